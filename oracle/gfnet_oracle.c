@@ -1,0 +1,279 @@
+/*
+ * gfnet_oracle.c -- CPU restatement of the GFNet hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP kernels in gfnet_amd/csrc.  It restates, in plain C,
+ * the algorithms of the reference (KN-Zhang/GFNet, Python/torch) function by function; each
+ * function cites the reference file:line it follows.  It is pinned against golden vectors that
+ * were produced by running the reference itself (tests/golden/make_golden.py -> tests/golden/
+ * *.npz; tests/test_oracle_golden.py).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (gfnet_amd/) never does.
+ *
+ * Built twice by oracle/build.py: -DREAL=float  -> liboracle_f32.so (mirrors the reference's
+ * fp32 arithmetic and operation order as closely as a scalar restatement can) and -DREAL=double
+ * -> liboracle_f64.so (same algorithm, double intermediates and outputs; used to measure noise
+ * floors).  Inputs are always float32 (feature/flow tensors) except the solver, which is double.
+ *
+ * Parity status: local_correlation / corr_volume / pos_embed / kde / grid_sample / interpolate
+ * are pinned by reference-generated goldens.  The homography solve (estimation.py:66-72) is
+ * OpenCV in the reference (third-party, absent here, version unpinned in requirements.txt:2):
+ * the solver below restates the *published* findHomography pipeline (RANSAC 4-point ->
+ * normalised DLT on inliers -> Gauss-Newton refinement) with a counter-based RNG of our own,
+ * so for that function parity with OpenCV is UNPINNED; it is pinned only by known-H fixtures.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef REAL
+#define REAL float
+#endif
+typedef REAL real;
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+#define EXPORT __attribute__((visibility("default")))
+
+EXPORT int oracle_real_bytes(void) { return (int)sizeof(real); }
+EXPORT int oracle_max_threads(void) {
+#if defined(_OPENMP)
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+EXPORT void oracle_set_threads(int n) {
+#if defined(_OPENMP)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* torch.linspace(start, end, steps) element i, computed the way ATen does for floating types:
+ * step = (end-start)/(steps-1); first half counts up from start, second half down from end. */
+static inline real linspace_at(real start, real end, int steps, int i) {
+    if (steps == 1) return start;
+    real step = (end - start) / (real)(steps - 1);
+    if (i < steps / 2) return start + step * (real)i;
+    return end - step * (real)(steps - i - 1);
+}
+
+/* F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) for one channel
+ * plane at normalised (gx, gy): ATen grid_sampler_2d: unnormalise ((g+1)*size-1)/2, corners
+ * nw/ne/sw/se with weights (x_e - x)(y_s - y) ..., out-of-bounds corners contribute 0. */
+static inline void bilinear_setup(real gx, real gy, int W, int H, int *x0, int *y0, real w[4]) {
+    real ix = ((gx + (real)1) * (real)W - (real)1) / (real)2;
+    real iy = ((gy + (real)1) * (real)H - (real)1) / (real)2;
+    real fx = floor(ix), fy = floor(iy);
+    /* guard the int conversion against inf/nan/huge: anything this far out samples zeros */
+    if (!(fx > (real)-1e8 && fx < (real)1e8)) { fx = (real)-1e8; ix = fx; }
+    if (!(fy > (real)-1e8 && fy < (real)1e8)) { fy = (real)-1e8; iy = fy; }
+    *x0 = (int)fx;
+    *y0 = (int)fy;
+    real xe = fx + 1, ys = fy + 1;
+    w[0] = (xe - ix) * (ys - iy); /* nw */
+    w[1] = (ix - fx) * (ys - iy); /* ne */
+    w[2] = (xe - ix) * (iy - fy); /* sw */
+    w[3] = (ix - fx) * (iy - fy); /* se */
+}
+
+static inline real bilinear_fetch(const float *plane, int W, int H, int x0, int y0, const real w[4]) {
+    real acc = 0;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) acc += (real)plane[(size_t)y0 * W + x0] * w[0];
+        if (x1 >= 0 && x1 < W) acc += (real)plane[(size_t)y0 * W + x1] * w[1];
+    }
+    if (y1 >= 0 && y1 < H) {
+        if (x0 >= 0 && x0 < W) acc += (real)plane[(size_t)y1 * W + x0] * w[2];
+        if (x1 >= 0 && x1 < W) acc += (real)plane[(size_t)y1 * W + x1] * w[3];
+    }
+    return acc;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * utils/local_correlation.py:4-72  local_correlation(featuremap_size, feature0, feature1,
+ *     local_radius, num_grid, flow=..., grid_based_correlation=..., num_level=1)
+ *   coords  = flow.permute(0,2,3,1) (:32) or the identity grid when flow is None (:21-30)
+ *   window  = meshgrid(linspace(-2r/h,2r/h,2r+1), linspace(-2r/w,2r/w,2r+1), 'ij'), stacked (x,y)
+ *             (:42-51)  [grid_based: +-2r/num_grid on both axes, :34-40]; tap k = iy*(2r+1)+ix
+ *   sample  = grid_sample(feature1[b], coords+window) (:55-58), zeros padding, align_corners=False
+ *   corr[b,k,i,j] = sum_c feature0[b,c,i,j]/sqrt(c) * sample[c,i,j,k]            (:60)
+ * f0: (B,C,G,G) with batch stride f0_bs floats; f1: (B,C,H,W); flow: (B,2,G,G) or NULL;
+ * out: (B,K,G,G) with batch stride out_bs (lets the caller write into a concat buffer).
+ * H,W: size of the f1 map that is sampled; win_h,win_w: the h,w the window offsets are built from.
+ */
+EXPORT void oracle_local_correlation(const float *f0, long f0_bs, const float *f1, const float *flow, real *out,
+                                     long out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
+                                     int win_w) {
+    const int D = 2 * r + 1, K = D * D;
+    const real inv_div = (real)sqrt((double)C); /* c**.5 as a python float, cast on use */
+    real ylo, yhi, xlo, xhi;
+    if (grid_based) {
+        ylo = (real)(-2.0 * r / G); yhi = (real)(2.0 * r / G);
+        xlo = ylo; xhi = yhi;
+    } else {
+        /* the window is laid out with the h,w of featuremap_size even on the pooled levels
+         * (local_correlation.py:44-45 vs :71), so win_h/win_w may differ from H/W */
+        ylo = (real)(-2.0 * r / win_h); yhi = (real)(2.0 * r / win_h);
+        xlo = (real)(-2.0 * r / win_w); xhi = (real)(2.0 * r / win_w);
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < G; ++i) {
+            for (int j = 0; j < G; ++j) {
+                real cx, cy;
+                if (flow) {
+                    cx = (real)flow[(((size_t)b * 2 + 0) * G + i) * G + j];
+                    cy = (real)flow[(((size_t)b * 2 + 1) * G + i) * G + j];
+                } else { /* identity grid: requires G == H == W in the reference */
+                    cx = linspace_at((real)(-1 + 1.0 / win_w), (real)(1 - 1.0 / win_w), win_w, j);
+                    cy = linspace_at((real)(-1 + 1.0 / win_h), (real)(1 - 1.0 / win_h), win_h, i);
+                }
+                for (int ky = 0; ky < D; ++ky) {
+                    real gy = cy + linspace_at(ylo, yhi, D, ky);
+                    for (int kx = 0; kx < D; ++kx) {
+                        real gx = cx + linspace_at(xlo, xhi, D, kx);
+                        int x0, y0;
+                        real w[4];
+                        bilinear_setup(gx, gy, W, H, &x0, &y0, w);
+                        real acc = 0;
+                        for (int c = 0; c < C; ++c) {
+                            real a = (real)f0[(size_t)b * f0_bs + ((size_t)c * G + i) * G + j] / inv_div;
+                            real s = bilinear_fetch(f1 + ((size_t)b * C + c) * H * W, W, H, x0, y0, w);
+                            acc += a * s;
+                        }
+                        out[(size_t)b * out_bs + ((size_t)(ky * D + kx) * G + i) * G + j] = acc;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* F.avg_pool2d(x, kernel_size=2, stride=2) used between levels (local_correlation.py:71). */
+EXPORT void oracle_avg_pool2(const float *in, float *out, int BC, int H, int W) {
+    int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < BC; ++p)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                const float *s = in + ((size_t)p * H + 2 * y) * W + 2 * x;
+                real v = ((real)s[0] + (real)s[1] + (real)s[W] + (real)s[W + 1]) / (real)4;
+                out[((size_t)p * Ho + y) * Wo + x] = (float)v;
+            }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * model/network.py:415-428  corr_volume: V[b,j,i] = sum_c f0[b,c,i]*f1[b,c,j] / sqrt(C),
+ *   stored (B,H1,W1,H0,W0) i.e. [b][j][i].  vol may be NULL (fused use).
+ * model/network.py:430-440  pos_embed: P = softmax over j; flow[b,:,i] = sum_j P[j,i]*grid[j],
+ *   grid[j] = (linspace(-1+1/W1,1-1/W1,W1)[j%W1], linspace(-1+1/H1,1-1/H1,H1)[j/W1]).
+ * flow out: (B,2,H0,W0).
+ */
+EXPORT void oracle_corr_softargmax(const float *f0, const float *f1, real *vol, real *flow, int B, int C, int H0,
+                                   int W0, int H1, int W1) {
+    const int N0 = H0 * W0, N1 = H1 * W1;
+    const real inv = (real)sqrt((double)C);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < N0; ++i) {
+            real *s = (real *)malloc(sizeof(real) * N1);
+            real m = -INFINITY;
+            for (int j = 0; j < N1; ++j) {
+                real acc = 0;
+                for (int c = 0; c < C; ++c)
+                    acc += (real)f0[((size_t)b * C + c) * N0 + i] * (real)f1[((size_t)b * C + c) * N1 + j];
+                acc = acc / inv;
+                s[j] = acc;
+                if (vol) vol[((size_t)b * N1 + j) * N0 + i] = acc;
+                if (acc > m) m = acc;
+            }
+            if (flow) {
+                real den = 0, ax = 0, ay = 0;
+                for (int j = 0; j < N1; ++j) {
+                    real e = (real)exp((double)(s[j] - m));
+                    den += e;
+                    ax += e * linspace_at((real)(-1 + 1.0 / W1), (real)(1 - 1.0 / W1), W1, j % W1);
+                    ay += e * linspace_at((real)(-1 + 1.0 / H1), (real)(1 - 1.0 / H1), H1, j / W1);
+                }
+                flow[((size_t)b * 2 + 0) * N0 + i] = ax / den;
+                flow[((size_t)b * 2 + 1) * N0 + i] = ay / den;
+            }
+            free(s);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * utils/kde.py:4-13  density_n = sum_m exp(-|x_n - y_m|^2 / (2 std^2)),  y = x[::down].
+ * The reference forms |.|^2 as cdist()**2 (mm-based cdist, noise floor ~4e-5 rel); this is the
+ * direct difference form, which is what cdist approximates.  x: (N,D) row-major, y: (M,D).
+ */
+EXPORT void oracle_kde(const float *x, int N, const float *y, int M, int D, double std, real *out) {
+    const real inv2s2 = (real)(1.0 / (2.0 * std * std));
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        real acc = 0;
+        for (int m = 0; m < M; ++m) {
+            real d2 = 0;
+            for (int d = 0; d < D; ++d) {
+                real t = (real)x[(size_t)n * D + d] - (real)y[(size_t)m * D + d];
+                d2 += t * t;
+            }
+            acc += (real)exp((double)(-d2 * inv2s2));
+        }
+        out[n] = acc;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * F.grid_sample(x, grid, mode='bilinear', align_corners=False) as used at model/network.py:537
+ * (x_hat) and :547 (grid_feature).  in: (B,C,H,W); grid: (B,Ho,Wo,2) (x,y); out: (B,C,Ho,Wo)
+ * with batch stride out_bs.
+ */
+EXPORT void oracle_grid_sample(const float *in, const float *grid, real *out, long out_bs, int B, int C, int H, int W,
+                               int Ho, int Wo) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < Ho; ++i)
+            for (int j = 0; j < Wo; ++j) {
+                const float *g = grid + (((size_t)b * Ho + i) * Wo + j) * 2;
+                int x0, y0;
+                real w[4];
+                bilinear_setup((real)g[0], (real)g[1], W, H, &x0, &y0, w);
+                for (int c = 0; c < C; ++c)
+                    out[(size_t)b * out_bs + ((size_t)c * Ho + i) * Wo + j] =
+                        bilinear_fetch(in + ((size_t)b * C + c) * H * W, W, H, x0, y0, w);
+            }
+}
+
+/* F.interpolate(x, size=(Ho,Wo), mode='bilinear', align_corners=False) (model/network.py:
+ * 238-249, 271-281, 333-335): ATen upsample_bilinear2d: scale = in/out, src = max(0, (dst+0.5)*
+ * scale - 0.5), i0 = floor(src), i1 = min(i0+1, in-1), lambda = src - i0. */
+EXPORT void oracle_interp_bilinear(const float *in, real *out, int BC, int H, int W, int Ho, int Wo) {
+    const real sy = (real)H / (real)Ho, sx = (real)W / (real)Wo;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < BC; ++p)
+        for (int y = 0; y < Ho; ++y) {
+            real fy = ((real)y + (real)0.5) * sy - (real)0.5;
+            if (fy < 0) fy = 0;
+            int y0 = (int)fy;
+            int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+            real ly = fy - (real)y0, hy = (real)1 - ly;
+            for (int x = 0; x < Wo; ++x) {
+                real fx = ((real)x + (real)0.5) * sx - (real)0.5;
+                if (fx < 0) fx = 0;
+                int x0 = (int)fx;
+                int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+                real lx = fx - (real)x0, hx = (real)1 - lx;
+                const float *s = in + (size_t)p * H * W;
+                out[((size_t)p * Ho + y) * Wo + x] =
+                    hy * (hx * (real)s[(size_t)y0 * W + x0] + lx * (real)s[(size_t)y0 * W + x1]) +
+                    ly * (hx * (real)s[(size_t)y1 * W + x0] + lx * (real)s[(size_t)y1 * W + x1]);
+            }
+        }
+}
