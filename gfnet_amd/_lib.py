@@ -1,0 +1,84 @@
+"""ctypes binding of libgfnet_hip.so (C ABI: include/gfnet_hip.h).
+
+torch is imported first so that the library binds to the HIP runtime torch already loaded
+(same libamdhip64 SONAME); torch itself is only plumbing here: device memory and streams.
+There is NO CPU fallback: if the library is missing or the tensors are not on a GPU the ops raise.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgfnet_hip.so")
+_lib = None
+
+c_int, c_i64, c_vp, c_float, c_double = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_double
+
+# name -> argtypes; every entry point returns int (GFN_OK or a negative error code)
+_SIGNATURES = {
+    "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp],
+    "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 11 + [c_vp],
+    "gfn_avg_pool2": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
+}
+
+
+class GfnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GfnError(f"{LIB_PATH} not found: build it with `python -m gfnet_amd.build` "
+                           "(there is no CPU fallback for the GFNet hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.gfn_abi_version.restype = c_int
+        L.gfn_last_error.restype = ctypes.c_char_p
+        L.gfn_device_arch.argtypes = [ctypes.c_char_p, c_int]
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ["gfn_abi_version", "gfn_last_error", "gfn_device_arch"] + list(_SIGNATURES)
+
+
+def check(code, what):
+    if code != 0:
+        raise GfnError(f"{what} failed ({code}): {lib().gfn_last_error().decode()}")
+
+
+def ptr(t):
+    return c_vp(t.data_ptr()) if t is not None else c_vp(0)
+
+
+def stream_ptr(device):
+    return c_vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GfnError("gfnet_amd ops need tensors on an AMD GPU (torch device 'cuda'); there is no CPU path")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GfnError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def f32c(t):
+    """fp32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,68 @@
+"""Build libgfnet_hip.so (hand-written HIP for gfx950) in-tree: python -m gfnet_amd.build
+
+hipcc cross-compiles without a GPU.  The library has a plain C ABI (include/gfnet_hip.h) and links
+only against the HIP runtime; it is loaded with ctypes by gfnet_amd/_lib.py.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libgfnet_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps(src):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "gfnet_hip.h"))
+    return [src, os.path.abspath(__file__)] + hdrs
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, verbose, extra):
+    obj = src[:-4] + ".o"
+    if _stale(obj, _deps(src)):
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj, True
+    return obj, False
+
+
+def build(force=False, verbose=False, extra=()):
+    srcs = sources()
+    if force:
+        for s in srcs:
+            o = s[:-4] + ".o"
+            if os.path.exists(o):
+                os.remove(o)
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, verbose, list(extra)), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    extra = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
+    print(build(force="--force" in sys.argv, verbose=True, extra=extra))

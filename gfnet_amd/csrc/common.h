@@ -1,0 +1,41 @@
+// Shared host-side helpers for the C-ABI entry points (gfx950 only; no CUDA dual path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/gfnet_hip.h"
+
+#define GFN_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace gfn {
+
+char *last_error_buf();  // thread-local, 512 bytes
+int fail(int code, const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GFN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return GFN_OK;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (guide T1): blocks are dealt round-robin over the
+// 8 XCDs, so block ids congruent mod 8 share an L2.  Give every XCD one contiguous run of the
+// work list, so that consecutive work items (tiles of the same image) hit the same L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
+    const unsigned q = n >> 3, rem = n & 7u;
+    const unsigned xcd = bid & 7u, local = bid >> 3;
+    const unsigned start = xcd * q + (xcd < rem ? xcd : rem);
+    return start + local;
+}
+
+// torch.linspace(start, end, steps)[i] in fp32, the way ATen fills it (from both ends).
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+}  // namespace gfn

@@ -1,0 +1,77 @@
+"""Drop-in for the reference's utils/local_correlation.py (same name, same signature).
+
+`local_correlation(...)` keeps the argument list of utils/local_correlation.py:4-16 so that
+model/network.py:553-554 can import it unchanged; the arithmetic runs in the hand-written gfx950
+kernels of csrc/local_corr.hip through the C ABI (gfn_local_corr_fwd, include/gfnet_hip.h).
+"""
+import torch
+
+from .. import _lib
+
+
+def _channel_stride_view(t):
+    """Return (tensor, batch_stride) for a (B,C,G,G) tensor whose channel/spatial dims are
+    contiguous but whose batch stride may be larger (a channel slice of a concat buffer)."""
+    B, C, G1, G2 = t.shape
+    if t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(2) == G2 and t.stride(1) == G1 * G2 and \
+            (B == 1 or t.stride(0) >= C * G1 * G2):
+        return t, (t.stride(0) if B > 1 else C * G1 * G2)
+    t = _lib.f32c(t)
+    return t, C * G1 * G2
+
+
+def local_correlation(featuremap_size, feature0, feature1, local_radius, num_grid, padding_mode="zeros", flow=None,
+                      im_A_coords=None, sample_mode="bilinear", grid_based_correlation=False, num_level=1, out=None,
+                      _variant=0):
+    """Local (2r+1)^2 correlation of grid features against feature1 sampled around `flow`.
+
+    Same contract as the reference (utils/local_correlation.py:4-72): returns (B, K*num_level,
+    num_grid, num_grid) with dtype/device of feature0; `im_A_coords` is accepted and ignored.
+    Extra keyword `out`: a (B, K*num_level, G, G) fp32 view to write into (e.g. the channel slice
+    of the refiner's concat buffer); it must have contiguous (K,G,G) planes.
+    Forward only: like the reference's sampling step this runs without autograd.
+    """
+    if padding_mode != "zeros" or sample_mode != "bilinear":
+        raise ValueError("only padding_mode='zeros', sample_mode='bilinear' (the reference's settings) are supported")
+    B, c, h, w = [int(v) for v in featuremap_size]
+    r = int(local_radius)
+    G = int(num_grid)
+    dev = _lib.require_gpu(feature0, feature1, flow)
+    K1 = (2 * r + 1) ** 2
+    K = K1 * int(num_level)
+    if tuple(feature0.shape) != (B, c, G, G):
+        raise ValueError(f"feature0 must be (B,c,num_grid,num_grid)={(B, c, G, G)}, got {tuple(feature0.shape)}")
+    if tuple(feature1.shape) != (B, c, h, w):
+        raise ValueError(f"feature1 must match featuremap_size {(B, c, h, w)}, got {tuple(feature1.shape)}")
+    if flow is not None and tuple(flow.shape) != (B, 2, G, G):
+        raise ValueError(f"flow must be (B,2,num_grid,num_grid), got {tuple(flow.shape)}")
+    if flow is None and not (G == h == w):
+        raise ValueError("flow=None assumes aligned maps: num_grid == h == w")
+    f0, f0_bs = _channel_stride_view(feature0.detach())
+    f1 = _lib.f32c(feature1.detach())
+    fl = _lib.f32c(flow.detach()) if flow is not None else None
+    ret_dtype = feature0.dtype
+    if out is None:
+        res = torch.empty((B, K, G, G), device=dev, dtype=torch.float32)
+        out_bs = K * G * G
+    else:
+        if tuple(out.shape) != (B, K, G, G) or out.dtype != torch.float32 or out.stride(3) != 1 or \
+                out.stride(2) != G or out.stride(1) != G * G:
+            raise ValueError("out must be a fp32 (B,K,G,G) view with contiguous (K,G,G) planes")
+        res = out
+        out_bs = out.stride(0) if B > 1 else K * G * G
+    L = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    hh, ww = h, w
+    for level in range(int(num_level)):
+        o = res[:, level * K1:(level + 1) * K1]
+        _lib.check(L.gfn_local_corr_fwd_ex(_lib.ptr(f0), f0_bs, _lib.ptr(f1), _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
+                                           out_bs, B, c, G, hh, ww, r, 1 if grid_based_correlation else 0, h, w,
+                                           int(_variant), st), "gfn_local_corr_fwd")
+        if level + 1 < num_level:
+            pooled = torch.empty((B, c, hh // 2, ww // 2), device=dev, dtype=torch.float32)
+            _lib.check(L.gfn_avg_pool2(_lib.ptr(f1), _lib.ptr(pooled), B * c, hh, ww, st), "gfn_avg_pool2")
+            f1, hh, ww = pooled, hh // 2, ww // 2
+    if out is None and ret_dtype != torch.float32:
+        res = res.to(ret_dtype)
+    return res

@@ -1,0 +1,158 @@
+"""GPU parity: gfnet_amd.utils.local_correlation (HIP, through the C ABI) vs the oracle and the
+reference-generated goldens.  Tolerance: |d| <= 1e-4 * max(1,|ref|) (BASELINE.json north_star:
+correlation tensors within 1e-4 rel fp32; abs+rel because values cross zero)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run(f0, f1, flow, r, G, **kw):
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B, c, h, w = f1.shape
+    out = local_correlation((B, c, h, w), dev(f0), dev(f1), r, G, flow=None if flow is None else dev(flow), **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_library_reports_gfx950():
+    import ctypes
+    from gfnet_amd import _lib
+
+    torch.zeros(1).cuda()
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.lib().gfn_device_arch(buf, 64), "gfn_device_arch")
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+def test_g1a_golden_general_path():
+    g = load_golden("g1a_local_corr_small")  # c=8 -> general per-tap kernel
+    out = run(g["f0"], g["f1"], g["flow"], int(g["r"]), int(g["G"]))
+    assert_close(out, g["out"], TOL, "g1a")
+
+
+def test_g1b_golden_scale4_fast_path():
+    g = load_golden("g1b_local_corr_scale4")
+    B, c, h, w, G, r = [int(v) for v in g["shape"]]
+    s0, s1, s2 = [int(v) for v in g["seeds"]]
+    f0 = synth.lattice_normalish((B, c, G, G), s0)
+    f1 = synth.lattice_normalish((B, c, h, w), s1)
+    flow = synth.homography_flow(B, G, s2)
+    flow[1] *= np.float32(1.1)
+    out = run(f0, f1, flow, r, G)
+    idx = g["probe_idx"]
+    assert_close(out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]], g["probe_val"], TOL, "probes")
+    assert_close(out[0, 40], g["out_b0_k40"], TOL, "plane b0 k40")
+    assert_close(out[1, 0], g["out_b1_k0"], TOL, "plane b1 k0")
+    np.testing.assert_allclose(out.astype(np.float64).sum(axis=(0, 2, 3)), g["sum_per_k"], rtol=0, atol=5e-2)
+    # and the whole tensor against the oracle, both kernel variants
+    ref = oracle.local_correlation((B, c, h, w), f0, f1, r, G, flow=flow)
+    assert_close(out, ref, TOL, "fast vs oracle")
+    assert_close(run(f0, f1, flow, r, G, _variant=1), ref, TOL, "general vs oracle")
+
+
+def test_g1c_golden_options():
+    g = load_golden("g1c_local_corr_options")
+    f0, f1, flow = g["f0"], g["f1"], g["flow"]
+    r, G = int(g["r"]), int(g["G"])
+    assert_close(run(f0, f1, flow, r, G, grid_based_correlation=True), g["out_grid_based"], TOL, "grid_based")
+    assert_close(run(f0, f1, flow, r, G, num_level=2), g["out_num_level2"], TOL, "num_level=2")
+    assert_close(run(f0, f1, None, r, G), g["out_flow_none"], TOL, "flow=None")
+    assert_close(run(f0, g["f1_rect"], flow, 2, G, grid_based_correlation=True), g["out_grid_based_rect"], TOL,
+                 "grid_based rect")
+
+
+@pytest.mark.parametrize("r", range(8))
+def test_g1d_golden_every_radius(r):
+    g = load_golden("g1d_local_corr_radii")  # c=16: r=1..7 take the tiled kernel, r=0 the general one
+    out = run(g["f0"], g["f1"], g["flow"], r, int(g["G"]))
+    assert_close(out, g[f"out_r{r}"], TOL, f"r={r}")
+
+
+# the four production shapes of basic.json at 448 and the three of the 560 upsample pass
+SHAPES = [(64, 32, 32, 7), (64, 56, 32, 6), (32, 112, 64, 4), (16, 224, 128, 2),
+          (64, 70, 40, 6), (32, 140, 80, 4), (16, 280, 160, 2)]
+
+
+@pytest.mark.parametrize("c,hs,G,r", SHAPES)
+@pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random"])
+def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
+    B = 2
+    f0 = synth.lattice_normalish((B, c, G, G), 31 + r)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 32 + r)
+    if flow_kind == "homography":
+        flow = synth.homography_flow(B, G, 33)
+    elif flow_kind == "zoom":  # magnified + partly outside: tiles fall back to per-round staging / per-tap
+        flow = synth.homography_flow(B, G, 34, scale=1.7)
+    else:  # uncorrelated flow: no two neighbouring cells share a window
+        flow = 1.2 * synth.lattice_uniform((B, 2, G, G), 35)
+    out = run(f0, f1, flow, r, G)
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    assert_close(out, ref, TOL, f"c{c} hs{hs} G{G} r{r} {flow_kind}")
+
+
+def test_ragged_sizes_and_rect_maps():
+    # G not a multiple of the tile, rectangular f1, batch of 3
+    B, c, h, w, G, r = 3, 16, 37, 53, 21, 3
+    f0 = synth.lattice_normalish((B, c, G, G), 41)
+    f1 = synth.lattice_normalish((B, c, h, w), 42)
+    flow = synth.homography_flow(B, G, 43, scale=1.05)
+    assert_close(run(f0, f1, flow, r, G), oracle.local_correlation((B, c, h, w), f0, f1, r, G, flow=flow), TOL, "ragged")
+
+
+def test_non_finite_and_far_flow_is_memory_safe():
+    B, c, hs, G, r = 1, 16, 24, 16, 2
+    f0 = synth.lattice_normalish((B, c, G, G), 51)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 52)
+    flow = synth.homography_flow(B, G, 53)
+    flow[0, 0, 0, 0] = 1e30
+    flow[0, 1, 3, 3] = -1e9
+    flow[0, 0, 5, 5] = 50.0
+    out = run(f0, f1, flow, r, G)
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    good = np.ones((G, G), bool)
+    good[0, 0] = good[3, 3] = False  # coordinates beyond float->int range: value unspecified, must not crash
+    assert_close(out[0][:, good], ref[0][:, good], TOL, "finite cells")
+    assert np.all(out[0][:, 5, 5] == 0)  # far outside the image: zeros padding
+
+
+def test_writes_into_concat_slice_and_reads_f0_from_it():
+    B, c, hs, G, r = 2, 16, 40, 24, 2
+    K = (2 * r + 1) ** 2
+    f0 = synth.lattice_normalish((B, c, G, G), 61)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 62)
+    flow = synth.homography_flow(B, G, 63)
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    d = torch.full((B, c + 5 + K, G, G), 7.0, device="cuda")
+    d[:, :c] = dev(f0)
+    local_correlation((B, c, hs, hs), d[:, :c], dev(f1), r, G, flow=dev(flow), out=d[:, c + 5:])
+    torch.cuda.synchronize()
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    assert_close(d[:, c + 5:].cpu().numpy(), ref, TOL, "slice")
+    assert torch.all(d[:, c:c + 5] == 7.0)
+
+
+def test_errors_are_python_exceptions():
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    f0 = torch.zeros(1, 16, 4, 4, device="cuda")
+    f1 = torch.zeros(1, 16, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        local_correlation((1, 16, 8, 8), f0, f1, 2, 4, flow=None)  # flow=None needs G == h == w
+    with pytest.raises(ValueError):
+        local_correlation((1, 16, 8, 8), f0, f1, 2, 5, flow=torch.zeros(1, 2, 5, 5, device="cuda"))
+    with pytest.raises(RuntimeError):
+        local_correlation((1, 16, 8, 8), f0.cpu(), f1.cpu(), 2, 4, flow=torch.zeros(1, 2, 4, 4))
