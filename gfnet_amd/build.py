@@ -14,7 +14,9 @@ LIB = os.path.join(CSRC, "libgfnet_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+         # no implicit FMA contraction: coordinate arithmetic must round exactly like the reference's
+         # fp32 ops (FMAs in the kernels are explicit fmaf calls)
+         "-ffp-contract=off", "-fno-gpu-rdc"]
 
 
 def sources():

@@ -20,6 +20,12 @@
 //     f0 is held in registers (16 per lane), accumulators in registers (<= 16 per round);
 //   * epilogue: D goes through LDS (aliasing the stage), each wave combines 64 cells x taps and
 //     stores 64-byte row segments of the (K,G,G) output.
+//   * the reference adds the window offsets in normalised fp32 coordinates, tap by tap, so its
+//     taps sit on whole-pixel steps only to ~3e-5 px (at W=280).  To stay bit-faithful the
+//     epilogue uses, per cell and per tap row/column, the fraction of exactly that fp32 sequence
+//     (a small LDS table); a cell for which some tap's floor() disagrees with (origin + tap
+//     index) -- the centre within rounding of a pixel boundary, or a non-finite flow -- is redone
+//     by the general per-tap routine at the end of the launch (about one cell in 10^4);
 //   * tiles whose bounding box does not fit the stage (wild flow) are staged per 2x16 round, and
 //     rounds that still do not fit use the general per-tap routine inside the same launch.
 // General path (any C, radius, non-integer tap spacing: grid_based_correlation, pooled levels):
@@ -37,6 +43,7 @@ constexpr int kChunk = 16;                // channels staged per pass
 constexpr int kSlotV4 = kChunk / 4 + 1;   // float4s per staged pixel: 4 data + 1 pad = 80 B
 constexpr int kStageBytes = 72 * 1024;    // stage buffer (aliased by the D buffer in the epilogue)
 constexpr int kCapSlots = kStageBytes / (kSlotV4 * 16) - 1;  // pixels that fit, minus the zero slot
+static_assert((kCapSlots + 1) * kSlotV4 < 65536, "stage indices are packed in 16 bits");
 constexpr int kTileW = 16;
 constexpr int kFar = 1 << 28;             // patch origin of a cell that samples nothing
 
@@ -168,16 +175,19 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     constexpr int TH = 2 * ROUNDS;           // tile height in cells
     constexpr int NC = 32 * ROUNDS;          // cells per tile
     constexpr int DS = P + 1;                // D-buffer cell stride (odd: conflict-free epilogue reads)
-    static_assert(NC * DS * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
+    constexpr int TS = 2 * D + 1;            // fraction-table cell stride (odd)
+    static_assert((NC * DS + NC * TS) * 4 <= kStageBytes, "D buffer + fraction table must fit in the stage they alias");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *s4 = reinterpret_cast<float4 *>(smem);
     float *dbuf = reinterpret_cast<float *>(smem);
     int *cellX0 = reinterpret_cast<int *>(smem + kStageBytes);
     int *cellY0 = cellX0 + NC;
-    float *cellPx = reinterpret_cast<float *>(cellY0 + NC);
-    float *cellPy = cellPx + NC;
-    int *bbox = reinterpret_cast<int *>(cellPy + NC);  // [ROUNDS][4] = x0,y0,x1,y1
+    float *cellNx = reinterpret_cast<float *>(cellY0 + NC);  // normalised centre (flow) of the cell
+    float *cellNy = cellNx + NC;
+    int *bbox = reinterpret_cast<int *>(cellNy + NC);  // [ROUNDS][4] = x0,y0,x1,y1
+    int *cellSlow = bbox + ROUNDS * 4;                  // [NC] 1 = redo this cell with the per-tap routine
+    float *tab = dbuf + NC * DS;                        // [NC][TS] per-tap fractions (aliases the stage)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
@@ -190,20 +200,22 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     // ---- per-cell setup: pixel coordinate, patch origin, bounding boxes ----------------------
     if (tid < ROUNDS * 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
     __syncthreads();
+    const float xlo = (float)(-2.0 * R / W), xhi = (float)(2.0 * R / W);
+    const float ylo = (float)(-2.0 * R / H), yhi = (float)(2.0 * R / H);
     if (tid < NC) {
         const int ci = tid >> 4, cj = tid & 15;
         const int gi = ty * TH + ci, gj = tx * kTileW + cj;
-        int X0 = kFar, Y0 = kFar;
-        float px = 0.f, py = 0.f;
+        int X0 = kFar, Y0 = kFar, slow = 0;
+        float nx = 0.f, ny = 0.f;
         if (gi < G && gj < G) {
-            float nx, ny;
             cell_coords(p, b, gi, gj, nx, ny);
-            px = unnorm(nx, W);
-            py = unnorm(ny, H);
-            const float fx = floorf(px), fy = floorf(py);
+            // patch origin = floor of the reference's own fp32 coordinate of tap 0, minus nothing:
+            // taps kx=0..2R then read columns kx and kx+1 of the patch
+            const float fx = floorf(unnorm(nx + gfn::linspace_at(xlo, xhi, D, 0), W));
+            const float fy = floorf(unnorm(ny + gfn::linspace_at(ylo, yhi, D, 0), H));
             if ((fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f)) {  // false for nan/inf
-                X0 = (int)fx - R;
-                Y0 = (int)fy - R;
+                X0 = (int)fx;
+                Y0 = (int)fy;
                 const int x0 = max(X0, 0), x1 = min(X0 + PW, W), y0 = max(Y0, 0), y1 = min(Y0 + PW, H);
                 if (x0 < x1 && y0 < y1) {
                     int *bb = bbox + (tid >> 5) * 4;
@@ -212,12 +224,15 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
                     atomicMax(bb + 2, x1);
                     atomicMax(bb + 3, y1);
                 }
+            } else {
+                slow = 1;  // non-finite / absurd flow: let the per-tap routine decide
             }
         }
         cellX0[tid] = X0;
         cellY0[tid] = Y0;
-        cellPx[tid] = px;
-        cellPy[tid] = py;
+        cellNx[tid] = nx;
+        cellNy[tid] = ny;
+        cellSlow[tid] = slow;
     }
     // the zero slot (index kCapSlots) is what every out-of-image tap reads
     if (tid < kSlotV4) s4[kCapSlots * kSlotV4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     int g, s16;
     lane_group(lane, g, s16);
     const int cr = wave * 4 + g;  // cell inside a round (0..31): row cr>>4, column cr&15
-    int addr[ROUNDS][NP];         // float4 index of each (round, pass) patch pixel
+    unsigned apk[ROUNDS][(NP + 1) / 2];  // float4 index (< 2^16) of each (round, pass) patch pixel, two per register
     float acc[ROUNDS][NP];
     const float *f0c[ROUNDS];     // this lane's f0 column (channel stride G*G), or null
 #pragma unroll
@@ -271,7 +286,11 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
             const int X = X0 + xx, Y = Y0 + yy;
             const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
             const int slot = in ? (Y - reg[rd].y0) * reg[rd].pitch + (X - reg[rd].x0) : kCapSlots;
-            addr[rd][t] = slot * kSlotV4;
+            const unsigned a = (unsigned)(slot * kSlotV4);
+            if (t & 1)
+                apk[rd][t >> 1] |= a << 16;
+            else
+                apk[rd][t >> 1] = a;
             acc[rd][t] = 0.f;
         }
     }
@@ -280,6 +299,12 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     const size_t cs = (size_t)G * G;
     const float *f1b = p.f1 + (size_t)b * p.C * H * W;
     for (int c0 = 0; c0 < p.C; c0 += kChunk) {
+        // keep the packed indices packed: without this the unpacking is hoisted out of the loop and
+        // the unpacked copies cost NP more registers per round (spills at r = 6, 7)
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+            for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (!fit[rd]) continue;
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
             }
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
-                const float4 *q = s4 + addr[rd][t];
+                const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
                 const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
                 float a = acc[rd][t];
                 a = fmaf(f[0], v0.x, a);  a = fmaf(f[1], v0.y, a);  a = fmaf(f[2], v0.z, a);  a = fmaf(f[3], v0.w, a);
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         }
     }
 
-    // ---- epilogue: D -> LDS, bilinear combination, coalesced stores ---------------------------
+    // ---- epilogue: D -> LDS, per-tap fractions, bilinear combination, coalesced stores -------
     __syncthreads();
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -315,6 +340,21 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
             const int pp = s16 + 16 * t;
             if (pp < P) dbuf[cell * DS + pp] = acc[rd][t];
         }
+    }
+    // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
+    // (local_correlation.py:55 adds window offsets in normalised units, grid_sample un-normalises)
+    for (int e = tid; e < NC * 2 * D; e += kThreads) {
+        const int cell = e / (2 * D), a = e - cell * (2 * D);
+        const bool isy = a >= D;
+        const int k = isy ? a - D : a;
+        const float n = isy ? cellNy[cell] : cellNx[cell];
+        const float pix = unnorm(n + (isy ? gfn::linspace_at(ylo, yhi, D, k) : gfn::linspace_at(xlo, xhi, D, k)),
+                                 isy ? H : W);
+        const float fl = floorf(pix);
+        const int origin = isy ? cellY0[cell] : cellX0[cell];
+        // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
+        if (origin != kFar && !(fl == (float)(origin + k))) cellSlow[cell] = 1;
+        tab[cell * TS + a] = pix - fl;
     }
     __syncthreads();
     {
@@ -326,42 +366,40 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         bool fast = false;
 #pragma unroll
         for (int q = 0; q < ROUNDS; ++q) fast |= (q == rd) & fit[q];
-        if (fast && gi < G && gj < G) {
-            const float px = cellPx[cell], py = cellPy[cell];
-            const float fx = floorf(px), fy = floorf(py);
-            const float wx1 = px - fx, wx0 = fx + 1.f - px, wy1 = py - fy, wy0 = fy + 1.f - py;
-            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+        if (fast && gi < G && gj < G && !cellSlow[cell]) {
             const float *dc = dbuf + cell * DS;
+            const float *tc = tab + cell * TS;
             float *o = p.out + (size_t)b * p.out_bs + (size_t)gi * G + gj;
             for (int k = wave % WPB; k < K; k += WPB) {
                 const int ky = k / D, kx = k - ky * D;
+                const float wx1 = tc[kx], wy1 = tc[D + ky];
+                const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
                 const float *d = dc + ky * PW + kx;
-                const float v = w00 * d[0] + w01 * d[1] + w10 * d[PW] + w11 * d[PW + 1];
+                // corner order and weights as grid_sample: nw, ne, sw, se
+                float v = d[0] * (wx0 * wy0);
+                v += d[1] * (wx1 * wy0);
+                v += d[PW] * (wx0 * wy1);
+                v += d[PW + 1] * (wx1 * wy1);
                 o[(size_t)k * cs] = v / p.sqrt_c;
             }
         }
     }
 
-    // ---- rounds whose search windows did not fit the stage: general per-tap routine ----------
-    bool any_slow = false;
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) any_slow |= !fit[rd];
-    if (any_slow) {
+    // ---- what the tiled path could not do: whole rounds whose windows did not fit the stage, and
+    //      single cells flagged above.  General per-tap routine, same launch. ----------------------
+    {
         LcParams q = p;
         q.r = R; q.win_h = H; q.win_w = W; q.grid_based = 0;
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (fit[rd]) continue;
-            for (int e = tid; e < 32 * K; e += kThreads) {
-                const int c32 = e & 31, k = e >> 5;
-                const int cell = rd * 32 + c32;
-                const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-                if (gi < G && gj < G) {
-                    float nx, ny;
-                    cell_coords(q, b, gi, gj, nx, ny);
-                    p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
-                        tap_general(q, b, gi, gj, k / D, k % D, D, nx, ny);
-                }
-            }
+        for (int cell = 0; cell < NC; ++cell) {
+            bool slow = cellSlow[cell] != 0;
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) slow |= ((cell >> 5) == rd) & !fit[rd];
+            if (!slow) continue;  // block-uniform
+            const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
+            if (gi >= G || gj >= G) continue;
+            for (int k = tid; k < K; k += kThreads)
+                p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
+                    tap_general(q, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
         }
     }
 }
@@ -372,7 +410,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
     p.tiles_y = (p.G + 2 * ROUNDS - 1) / (2 * ROUNDS);
-    const size_t lds = kStageBytes + NC * 16 + ROUNDS * 16;
+    const size_t lds = kStageBytes + NC * 20 + ROUNDS * 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
