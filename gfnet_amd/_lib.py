@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgfnet_hip.so")
+LIB_PATH = os.environ.get("GFNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libgfnet_hip.so")
 _lib = None
 
 c_int, c_i64, c_vp, c_float, c_double = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_double

@@ -47,6 +47,16 @@ def _compile(src, verbose, extra):
     return obj, False
 
 
+def build_ablate(verbose=False):
+    """Timing-experiment build (tools/ only): same sources with -DGFN_ABLATE -> libgfnet_hip_ablate.so."""
+    out = os.path.join(CSRC, "libgfnet_hip_ablate.so")
+    cmd = [HIPCC] + FLAGS + ["-DGFN_ABLATE", "-shared", "-o", out] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force=False, verbose=False, extra=()):
     srcs = sources()
     if force:
@@ -66,5 +76,8 @@ def build(force=False, verbose=False, extra=()):
 
 
 if __name__ == "__main__":
+    if "--ablate" in sys.argv:
+        print(build_ablate(verbose=True))
+        sys.exit(0)
     extra = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
     print(build(force="--force" in sys.argv, verbose=True, extra=extra))

@@ -58,7 +58,16 @@ struct LcParams {
     float sqrt_c;
     // general path only
     int r, win_h, win_w, grid_based;
+#ifdef GFN_ABLATE
+    int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
+#endif
 };
+
+#ifdef GFN_ABLATE
+#define ABL(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define ABL(p, bit) false
+#endif
 
 struct Region {
     int x0, y0, w, h, pitch;
@@ -143,26 +152,36 @@ __global__ __launch_bounds__(256) void local_corr_general_kernel(LcParams p) {
 }
 
 // ---- fast tiled kernel -----------------------------------------------------------------------
+template <int UN>  // wave-iterations in flight: all their loads are issued before the first LDS write
 __device__ __forceinline__ void stage_region(float4 *s4, const float *f1c, int H, int W, const Region &rg, int wave,
                                              int lane) {
     const int npx = rg.w * rg.h;
     const int nwi = ((npx + 63) >> 6) * 4;  // wave-iterations: 4 channel groups x runs of 64 pixels
     const float inv_w = 1.0f / (float)rg.w;
     const size_t plane = (size_t)H * W;
-    for (int wi = wave; wi < nwi; wi += kWaves) {
-        const int cg = wi & 3;
-        const int q = ((wi >> 2) << 6) + lane;
-        if (q < npx) {
-            const int y = (int)(((float)q + 0.5f) * inv_w);  // exact for q < 2^16, w < 2^10
-            const int x = q - y * rg.w;
-            const float *src = f1c + (size_t)(cg * 4) * plane + (size_t)(rg.y0 + y) * W + (rg.x0 + x);
-            float4 v;
-            v.x = src[0];
-            v.y = src[plane];
-            v.z = src[2 * plane];
-            v.w = src[3 * plane];
-            s4[(y * rg.pitch + x) * kSlotV4 + cg] = v;
+    for (int wi0 = wave; wi0 < nwi; wi0 += kWaves * UN) {
+        float4 v[UN];
+        int dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int wi = wi0 + u * kWaves;
+            const int cg = wi & 3;
+            const int q = ((wi >> 2) << 6) + lane;
+            dst[u] = -1;
+            if (wi < nwi && q < npx) {
+                const int y = (int)(((float)q + 0.5f) * inv_w);  // exact for q < 2^16, w < 2^10
+                const int x = q - y * rg.w;
+                const float *src = f1c + (size_t)(cg * 4) * plane + (size_t)(rg.y0 + y) * W + (rg.x0 + x);
+                v[u].x = src[0];
+                v[u].y = src[plane];
+                v[u].z = src[2 * plane];
+                v[u].w = src[3 * plane];
+                dst[u] = (y * rg.pitch + x) * kSlotV4 + cg;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (dst[u] >= 0) s4[dst[u]] = v[u];
     }
 }
 
@@ -187,6 +206,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     float *cellNy = cellNx + NC;
     int *bbox = reinterpret_cast<int *>(cellNy + NC);  // [ROUNDS][4] = x0,y0,x1,y1
     int *cellSlow = bbox + ROUNDS * 4;                  // [NC] 1 = redo this cell with the per-tap routine
+    int *nSlow = cellSlow + NC;                         // number of such cells in the tile
     float *tab = dbuf + NC * DS;                        // [NC][TS] per-tap fractions (aliases the stage)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,6 +219,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
 
     // ---- per-cell setup: pixel coordinate, patch origin, bounding boxes ----------------------
     if (tid < ROUNDS * 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
+    if (tid == 0) *nSlow = 0;
     __syncthreads();
     const float xlo = (float)(-2.0 * R / W), xhi = (float)(2.0 * R / W);
     const float ylo = (float)(-2.0 * R / H), yhi = (float)(2.0 * R / H);
@@ -226,6 +247,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
                 }
             } else {
                 slow = 1;  // non-finite / absurd flow: let the per-tap routine decide
+                atomicAdd(nSlow, 1);
             }
         }
         cellX0[tid] = X0;
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
     const float *f1b = p.f1 + (size_t)b * p.C * H * W;
+    constexpr int UN = (ROUNDS * NP >= 32) ? 1 : ((ROUNDS * NP >= 24 || ROUNDS > 2) ? 2 : 4);
     for (int c0 = 0; c0 < p.C; c0 += kChunk) {
         // keep the packed indices packed: without this the unpacking is hoisted out of the loop and
         // the unpacked copies cost NP more registers per round (spills at r = 6, 7)
@@ -305,17 +328,23 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));
+        if (whole) {  // the usual case: one stage per channel chunk serves every round
+            __syncthreads();  // everyone is done reading the previous contents
+            if (!ABL(p, 1)) stage_region<UN>(s4, f1b + (size_t)c0 * H * W, H, W, reg[0], wave, lane);
+            __syncthreads();
+        }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (!fit[rd]) continue;
             float f[kChunk];
 #pragma unroll
-            for (int k = 0; k < kChunk; ++k) f[k] = f0c[rd] ? f0c[rd][(size_t)(c0 + k) * cs] : 0.f;
-            if (whole ? (rd == 0) : true) {
-                __syncthreads();  // everyone is done reading the previous contents
-                stage_region(s4, f1b + (size_t)c0 * H * W, H, W, reg[rd], wave, lane);
+            for (int k = 0; k < kChunk; ++k) f[k] = (f0c[rd] && !ABL(p, 4)) ? f0c[rd][(size_t)(c0 + k) * cs] : 0.f;
+            if (!whole) {
+                __syncthreads();
+                if (!ABL(p, 1)) stage_region<1>(s4, f1b + (size_t)c0 * H * W, H, W, reg[rd], wave, lane);
                 __syncthreads();
             }
+            if (ABL(p, 2)) continue;
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     }
     // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
     // (local_correlation.py:55 adds window offsets in normalised units, grid_sample un-normalises)
-    for (int e = tid; e < NC * 2 * D; e += kThreads) {
+    for (int e = tid; e < NC * 2 * D && !ABL(p, 32); e += kThreads) {
         const int cell = e / (2 * D), a = e - cell * (2 * D);
         const bool isy = a >= D;
         const int k = isy ? a - D : a;
@@ -353,7 +382,10 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         const float fl = floorf(pix);
         const int origin = isy ? cellY0[cell] : cellX0[cell];
         // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
-        if (origin != kFar && !(fl == (float)(origin + k))) cellSlow[cell] = 1;
+        if (origin != kFar && !(fl == (float)(origin + k))) {
+            cellSlow[cell] = 1;
+            atomicAdd(nSlow, 1);
+        }
         tab[cell * TS + a] = pix - fl;
     }
     __syncthreads();
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         bool fast = false;
 #pragma unroll
         for (int q = 0; q < ROUNDS; ++q) fast |= (q == rd) & fit[q];
-        if (fast && gi < G && gj < G && !cellSlow[cell]) {
+        if (fast && gi < G && gj < G && !cellSlow[cell] && !ABL(p, 8)) {
             const float *dc = dbuf + cell * DS;
             const float *tc = tab + cell * TS;
             float *o = p.out + (size_t)b * p.out_bs + (size_t)gi * G + gj;
@@ -387,10 +419,13 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
 
     // ---- what the tiled path could not do: whole rounds whose windows did not fit the stage, and
     //      single cells flagged above.  General per-tap routine, same launch. ----------------------
-    {
+    bool any_slow = *nSlow != 0;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) any_slow |= !fit[rd];
+    if (any_slow) {  // block-uniform, rare
         LcParams q = p;
         q.r = R; q.win_h = H; q.win_w = W; q.grid_based = 0;
-        for (int cell = 0; cell < NC; ++cell) {
+        for (int cell = 0; cell < NC && !ABL(p, 16); ++cell) {
             bool slow = cellSlow[cell] != 0;
 #pragma unroll
             for (int rd = 0; rd < ROUNDS; ++rd) slow |= ((cell >> 5) == rd) & !fit[rd];
@@ -410,7 +445,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
     p.tiles_y = (p.G + 2 * ROUNDS - 1) / (2 * ROUNDS);
-    const size_t lds = kStageBytes + NC * 20 + ROUNDS * 16;
+    const size_t lds = kStageBytes + NC * 20 + ROUNDS * 16 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
@@ -447,6 +482,10 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     p.tiles_x = p.tiles_y = 0;
     p.sqrt_c = (float)sqrt((double)C);
     p.r = r; p.win_h = win_h; p.win_w = win_w; p.grid_based = grid_based;
+#ifdef GFN_ABLATE
+    p.dbg = variant >> 8;
+    variant &= 0xff;
+#endif
 
     const bool fast_ok = variant == 0 && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7;
     if (fast_ok) {
