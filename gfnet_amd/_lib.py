@@ -20,6 +20,25 @@ _SIGNATURES = {
     "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp],
     "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp],
     "gfn_avg_pool2": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "gfn_corr_softargmax_fwd": [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
+    "gfn_corr_volume_fwd": [c_vp, c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
+    "gfn_pos_embed_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
+    "gfn_refiner_input_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_vp],
+    "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
+    "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
+    "gfn_flow_update_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],
+    "gfn_match_post_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_int] * 4 + [c_vp],
+    "gfn_kde_msplit": [c_int, c_int, c_int],
+    "gfn_kde_density": [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64, c_i64, c_double, c_vp, c_i64, c_vp],
+    "gfn_convert_matches": [c_vp, c_vp, c_i64] + [c_float] * 4 + [c_vp],
+    "gfn_homography_ransac": [c_vp, c_int, c_int, c_double, c_int, ctypes.c_uint64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                              c_vp, c_i64, c_vp],
+    "gfn_homography_dlt": [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
+}
+# entry points that return a size instead of a status
+_SIZE_FUNCS = {
+    "gfn_kde_scratch_floats": [c_int, c_int, c_int, c_int],
+    "gfn_homography_scratch_bytes": [c_int, c_int],
 }
 
 
@@ -42,12 +61,16 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = c_int
+        for name, argtypes in _SIZE_FUNCS.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = c_i64
         _lib = L
     return _lib
 
 
 def exported_symbols():
-    return ["gfn_abi_version", "gfn_last_error", "gfn_device_arch"] + list(_SIGNATURES)
+    return ["gfn_abi_version", "gfn_last_error", "gfn_device_arch"] + list(_SIGNATURES) + list(_SIZE_FUNCS)
 
 
 def check(code, what):

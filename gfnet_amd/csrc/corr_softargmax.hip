@@ -1,0 +1,192 @@
+// corr_softargmax.hip -- global correlation volume and its soft-argmax for gfx950.
+//
+// Replaces model/network.py:415-428 (GFNet.corr_volume) and :430-440 (GFNet.pos_embed):
+//   V[b,j,i]   = sum_c f0[b,c,i] * f1[b,c,j] / sqrt(C)          (stored (B,H1,W1,H0,W0))
+//   flow[b,:,i] = sum_j softmax_j(V[b,j,i]) * grid[j],  grid[j] = B-image cell centre (x,y)
+// The reference writes the volume (4 MiB per direction at 32^2 x 32^2, 21 MiB at 48^2 x 48^2) and
+// reads it back for a softmax over a strided dim.  The fused kernel never writes it: each wave
+// owns 32 A-positions (i) and streams all B-positions (j) in tiles of 32 through the exact-fp32
+// matrix core (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain, so no precision is given up),
+// with an online softmax (running max / sum / weighted coordinate sums) kept per lane.
+//
+// MFMA operand mapping (32x32x2 f32, cdna_hip_programming.md section 3): lane l supplies
+// A[row=l&31][k=l>>5] and B[k=l>>5][col=l&31]; with rows = j and cols = i both operands are plain
+// coalesced loads from the NCHW maps (positions contiguous), no LDS and no transposition.
+// Accumulator register r of lane l holds S[j = (r&3)+8(r>>2)+4(l>>5)][i = l&31]: the column
+// (i) sits on the lane, so the softmax over j is lane-local apart from one final lane^32 merge.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// KS = k-steps of 2 channels held in registers (compile-time so that the operand array stays in
+// VGPRs: a runtime-indexed register array would go to scratch).
+template <int KS, bool WRITE_VOL, bool WRITE_FLOW>
+__global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                              float *__restrict__ vol, float *__restrict__ flow, int B,
+                                                              int C, int H0, int W0, int H1, int W1, float sqrt_c) {
+    const int N0 = H0 * W0, N1 = H1 * W1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int itiles = (N0 + 31) >> 5;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= B * itiles) return;  // no barriers in this kernel
+    const int b = wid / itiles, i0 = (wid - b * itiles) << 5;
+    const int col = lane & 31, h = lane >> 5;
+    const int i = i0 + col;
+    const int ic = min(i, N0 - 1);
+
+    const float *f0b = f0 + (size_t)b * C * N0;
+    const float *f1b = f1 + (size_t)b * C * N1;
+
+    // B operand: this wave's 32 columns of f0, all channels, kept in registers
+    float bop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 2 * s + h;
+        bop[s] = (c < C) ? f0b[(size_t)c * N0 + ic] : 0.f;
+    }
+
+    const float x_lo = (float)(-1 + 1.0 / W1), x_hi = (float)(1 - 1.0 / W1);
+    const float y_lo = (float)(-1 + 1.0 / H1), y_hi = (float)(1 - 1.0 / H1);
+    const float inv_w1 = 1.0f / (float)W1;
+    float m = -INFINITY, l = 0.f, ax = 0.f, ay = 0.f;
+
+    for (int j0 = 0; j0 < N1; j0 += 32) {
+        const int jl = min(j0 + col, N1 - 1);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 2 * s + h;
+            const float a = (c < C) ? f1b[(size_t)c * N1 + jl] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bop[s], acc, 0, 0, 0);
+        }
+        float sv[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = acc[r] / sqrt_c;
+            if (WRITE_VOL) {
+                if (j < N1 && i < N0) vol[((size_t)b * N1 + j) * N0 + i] = v;
+            }
+            sv[r] = (j < N1) ? v : -INFINITY;
+            mt = fmaxf(mt, sv[r]);
+        }
+        if (WRITE_FLOW) {
+            const float mn = fmaxf(m, mt);
+            const float sc = __expf(m - mn);  // m = -inf on the first tile -> 0
+            l *= sc; ax *= sc; ay *= sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int jy = (int)(((float)j + 0.5f) * inv_w1);
+                const int jx = j - jy * W1;
+                const float e = __expf(sv[r] - mn);  // exp(-inf) = 0 for the padded rows
+                l += e;
+                ax = fmaf(e, gfn::linspace_at(x_lo, x_hi, W1, jx), ax);
+                ay = fmaf(e, gfn::linspace_at(y_lo, y_hi, H1, min(jy, H1 - 1)), ay);
+            }
+            m = mn;
+        }
+    }
+    if (WRITE_FLOW) {
+        // merge the two half-waves (same column i, disjoint rows j)
+        const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
+        const float mn = fmaxf(m, m2);
+        const float s1 = __expf(m - mn), s2 = __expf(m2 - mn);
+        const float lt = l * s1 + l2 * s2;
+        const float fx = (ax * s1 + ax2 * s2) / lt, fy = (ay * s1 + ay2 * s2) / lt;
+        if (h == 0 && i < N0) {
+            flow[((size_t)b * 2 + 0) * N0 + i] = fx;
+            flow[((size_t)b * 2 + 1) * N0 + i] = fy;
+        }
+    }
+}
+
+// pos_embed on an explicit volume (model/network.py:430-440): one thread per (b, i), coalesced
+// over i, online softmax over j.  Only used when a caller hands in a volume of its own.
+__global__ __launch_bounds__(256) void pos_embed_kernel(const float *__restrict__ vol, float *__restrict__ flow, int B,
+                                                        int H0, int W0, int H1, int W1) {
+    const int N0 = H0 * W0, N1 = H1 * W1;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N0) return;
+    const int b = (int)(idx / N0), i = (int)(idx - (long)b * N0);
+    const float x_lo = (float)(-1 + 1.0 / W1), x_hi = (float)(1 - 1.0 / W1);
+    const float y_lo = (float)(-1 + 1.0 / H1), y_hi = (float)(1 - 1.0 / H1);
+    const float *v = vol + (size_t)b * N1 * N0 + i;
+    float m = -INFINITY, l = 0.f, ax = 0.f, ay = 0.f;
+    int jx = 0, jy = 0;
+    for (int j = 0; j < N1; ++j) {
+        const float s = v[(size_t)j * N0];
+        if (s > m) {
+            const float sc = __expf(m - s);
+            l *= sc; ax *= sc; ay *= sc;
+            m = s;
+        }
+        const float e = __expf(s - m);
+        l += e;
+        ax = fmaf(e, gfn::linspace_at(x_lo, x_hi, W1, jx), ax);
+        ay = fmaf(e, gfn::linspace_at(y_lo, y_hi, H1, jy), ay);
+        if (++jx == W1) { jx = 0; ++jy; }
+    }
+    flow[((size_t)b * 2 + 0) * N0 + i] = ax / l;
+    flow[((size_t)b * 2 + 1) * N0 + i] = ay / l;
+}
+
+int check_args(const void *f0, const void *f1, int B, int C, int H0, int W0, int H1, int W1) {
+    if (!f0 || !f1) return gfn::fail(GFN_ERR_INVALID_ARG, "corr: null feature pointer");
+    if (B < 0 || C <= 0 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "corr: bad size B=%d C=%d %dx%d vs %dx%d", B, C, H0, W0, H1, W1);
+    if (C > 128) return gfn::fail(GFN_ERR_INVALID_ARG, "corr: C=%d > 128 channels not supported", C);
+    if ((long)H0 * W0 >= (1L << 24) || (long)H1 * W1 >= (1L << 24))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "corr: map too large");
+    return GFN_OK;
+}
+
+template <bool WV, bool WF>
+int launch_corr(const float *f0, const float *f1, float *vol, float *flow, int B, int C, int H0, int W0, int H1, int W1,
+                hipStream_t stream) {
+    const int waves = B * ((H0 * W0 + 31) / 32);
+    const dim3 grid((waves + 3) / 4), block(256);
+    const float sc = (float)sqrt((double)C);
+    if (C <= 16)
+        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+    else if (C <= 32)
+        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+    else if (C <= 64)
+        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+    else
+        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+    return gfn::check_launch("corr_softargmax_kernel");
+}
+
+}  // namespace
+
+GFN_EXPORT int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B, int C, int H0, int W0,
+                                       int H1, int W1, gfn_stream_t stream) {
+    if (int e = check_args(f0, f1, B, C, H0, W0, H1, W1)) return e;
+    if (!flow) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: null flow");
+    if (B == 0) return GFN_OK;
+    return launch_corr<false, true>(f0, f1, nullptr, flow, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+}
+
+GFN_EXPORT int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C,
+                                   int H0, int W0, int H1, int W1, gfn_stream_t stream) {
+    if (int e = check_args(f0, f1, B, C, H0, W0, H1, W1)) return e;
+    if (!vol) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_volume: null volume");
+    if (B == 0) return GFN_OK;
+    if (flow_or_null) return launch_corr<true, true>(f0, f1, vol, flow_or_null, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+    return launch_corr<true, false>(f0, f1, vol, nullptr, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+}
+
+GFN_EXPORT int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1,
+                                 gfn_stream_t stream) {
+    if (!vol || !flow || B < 0 || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "pos_embed: bad argument");
+    if (B == 0) return GFN_OK;
+    const long total = (long)B * H0 * W0;
+    hipLaunchKernelGGL(pos_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vol,
+                       flow, B, H0, W0, H1, W1);
+    return gfn::check_launch("pos_embed_kernel");
+}

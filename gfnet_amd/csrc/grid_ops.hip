@@ -1,0 +1,250 @@
+// grid_ops.hip -- the small gather / elementwise kernels around the correlation on the hot path
+// (gfx950).  All are HBM/L2-bound one-pass kernels with coalesced stores along the grid row.
+//
+//   gfn_refiner_input_fwd  ConvRefiner.forward prefix, model/network.py:533-555: the two
+//                          grid_samples, the displacement embedding (1x1 conv of 2 channels) --
+//                          written straight into the channel slices of the concat buffer `d`
+//                          (the local-correlation kernel fills the last slice), so the
+//                          reference's torch.cat copy of up to 417 channels disappears.
+//   gfn_grid_sample_fwd    F.grid_sample(bilinear, zeros, align_corners=False)
+//   gfn_interp_bilinear_fwd F.interpolate(mode='bilinear', align_corners=False), network.py:238-249,271-281
+//   gfn_flow_update_fwd    displacement scaling / eval-time zeroing / accumulation, network.py:262-268
+//   gfn_match_post_fwd     certainty attenuation, sigmoid, out-of-range masking, clamp, warp
+//                          assembly, network.py:332-338 + 358-384
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * (float)size - 1.f) / 2.f; }
+
+struct Bilin {
+    int x0, y0;
+    float w00, w01, w10, w11;
+    bool xa, xb, ya, yb;
+};
+
+// grid_sample's bilinear set-up (ATen grid_sampler_2d): corners nw,ne,sw,se; zeros padding.
+__device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int W, int H) {
+    Bilin s;
+    const float ix = unnorm(gx, W), iy = unnorm(gy, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const bool sane = (fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f);
+    s.x0 = sane ? (int)fx : -4;
+    s.y0 = sane ? (int)fy : -4;
+    s.w00 = (fx + 1.f - ix) * (fy + 1.f - iy);
+    s.w01 = (ix - fx) * (fy + 1.f - iy);
+    s.w10 = (fx + 1.f - ix) * (iy - fy);
+    s.w11 = (ix - fx) * (iy - fy);
+    s.xa = (unsigned)s.x0 < (unsigned)W;
+    s.xb = (unsigned)(s.x0 + 1) < (unsigned)W;
+    s.ya = (unsigned)s.y0 < (unsigned)H;
+    s.yb = (unsigned)(s.y0 + 1) < (unsigned)H;
+    return s;
+}
+
+__device__ __forceinline__ float bilin_fetch(const float *pl, int W, const Bilin &s) {
+    const long o = (long)s.y0 * W + s.x0;
+    float v = 0.f;
+    if (s.ya & s.xa) v += pl[o] * s.w00;
+    if (s.ya & s.xb) v += pl[o + 1] * s.w01;
+    if (s.yb & s.xa) v += pl[o + W] * s.w10;
+    if (s.yb & s.xb) v += pl[o + W + 1] * s.w11;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                            const float *__restrict__ flow, const float *__restrict__ dw,
+                                                            const float *__restrict__ db, float *__restrict__ d, long d_bs,
+                                                            int B, int C, int Hs, int Ws, int G, int Dd, float disp_scale) {
+    const int CH = 2 * C + Dd;
+    const long total = (long)B * CH * G * G;
+    const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % G);
+        long t = idx / G;
+        const int i = (int)(t % G);
+        t /= G;
+        const int ch = (int)(t % CH);
+        const int b = (int)(t / CH);
+        const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
+        const float fx = flow[(((size_t)b * 2 + 0) * G + i) * G + j], fy = flow[(((size_t)b * 2 + 1) * G + i) * G + j];
+        float v;
+        if (ch < C) {  // grid_feature = grid_sample(x, im_A_coords)            network.py:547
+            const Bilin s = bilin_setup(cx, cy, Ws, Hs);
+            v = bilin_fetch(f0 + ((size_t)b * C + ch) * Hs * Ws, Ws, s);
+        } else if (ch < 2 * C) {  // x_hat = grid_sample(y, flow)               network.py:537
+            const Bilin s = bilin_setup(fx, fy, Ws, Hs);
+            v = bilin_fetch(f1 + ((size_t)b * C + (ch - C)) * Hs * Ws, Ws, s);
+        } else {  // disp_emb(40/32 * scale_factor * (flow - im_A_coords))       network.py:548-549
+            const int o = ch - 2 * C;
+            const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
+            v = dw[o * 2 + 0] * dx + dw[o * 2 + 1] * dy + db[o];
+        }
+        d[(size_t)b * d_bs + ((size_t)ch * G + i) * G + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
+                                                          float *__restrict__ out, long out_bs, int B, int C, int H, int W,
+                                                          int Ho, int Wo) {
+    const long total = (long)B * C * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % Wo);
+        long t = idx / Wo;
+        const int i = (int)(t % Ho);
+        t /= Ho;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        const float *g = grid + (((size_t)b * Ho + i) * Wo + j) * 2;
+        const Bilin s = bilin_setup(g[0], g[1], W, H);
+        out[(size_t)b * out_bs + ((size_t)c * Ho + i) * Wo + j] = bilin_fetch(in + ((size_t)b * C + c) * H * W, W, s);
+    }
+}
+
+// ATen upsample_bilinear2d, align_corners=False: src = max(0, (dst+0.5)*in/out - 0.5)
+__device__ __forceinline__ float interp_at(const float *pl, int H, int W, int Ho, int Wo, int y, int x) {
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * pl[(size_t)y0 * W + x0] + lx * pl[(size_t)y0 * W + x1]) +
+           ly * (hx * pl[(size_t)y1 * W + x0] + lx * pl[(size_t)y1 * W + x1]);
+}
+
+__global__ __launch_bounds__(256) void interp_bilinear_kernel(const float *__restrict__ in, float *__restrict__ out, int BC,
+                                                              int H, int W, int Ho, int Wo) {
+    const long total = (long)BC * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wo);
+        const long t = idx / Wo;
+        const int y = (int)(t % Ho);
+        const long pl = t / Ho;
+        out[idx] = interp_at(in + (size_t)pl * H * W, H, W, Ho, Wo, y, x);
+    }
+}
+
+// delta: (B, >=3, G, G) refiner output (channels 0,1 = displacement, 2 = certainty), batch stride delta_bs.
+__global__ __launch_bounds__(256) void flow_update_kernel(float *__restrict__ flow, float *__restrict__ cert,
+                                                          const float *__restrict__ delta, long delta_bs,
+                                                          float *__restrict__ disp_prev, int B, int G, float scale,
+                                                          float div_x, float div_y, int zero_small, int first) {
+    const long GG = (long)G * G, total = (long)B * GG;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / GG);
+        const long r = idx - (long)b * GG;
+        const float *dl = delta + (size_t)b * delta_bs + r;
+        float dx = scale * (dl[0] / div_x), dy = scale * (dl[GG] / div_y);  // network.py:262-263
+        float *pp = disp_prev + (size_t)b * 2 * GG + r;
+        if (zero_small) {  // network.py:256,264-265
+            const float px = first ? 1e-7f : pp[0], py = first ? 1e-7f : pp[GG];
+            if (fabsf(dx - px) / fabsf(px) < 1e-6f) dx = 0.f;
+            if (fabsf(dy - py) / fabsf(py) < 1e-6f) dy = 0.f;
+        }
+        pp[0] = dx;
+        pp[GG] = dy;
+        float *fl = flow + (size_t)b * 2 * GG + r;
+        fl[0] += dx;
+        fl[GG] += dy;
+        cert[idx] += dl[2 * GG];
+    }
+}
+
+__global__ __launch_bounds__(256) void match_post_kernel(const float *__restrict__ flow, const float *__restrict__ cert,
+                                                         const float *__restrict__ cert16, float *__restrict__ warp,
+                                                         float *__restrict__ cert_out, int Bimg, int G, int Gc,
+                                                         int symmetric) {
+    const int Gw = symmetric ? 2 * G : G;
+    const long total = (long)Bimg * G * Gw;
+    const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int jw = (int)(idx % Gw);
+        long t = idx / Gw;
+        const int i = (int)(t % G);
+        const int b = (int)(t / G);
+        const bool second = jw >= G;  // the B->A half of a symmetric warp
+        const int j = second ? jw - G : jw;
+        const int fb = second ? Bimg + b : b;
+        const size_t cell = (size_t)i * G + j, GG = (size_t)G * G;
+        float fx = flow[((size_t)fb * 2 + 0) * GG + cell], fy = flow[((size_t)fb * 2 + 1) * GG + cell];
+        float c = cert[(size_t)fb * GG + cell];
+        if (cert16) {  // network.py:332-338
+            const float low = interp_at(cert16 + (size_t)fb * Gc * Gc, Gc, Gc, G, G, i, j);
+            c = c - 0.5f * low * (low < 0.f ? 1.f : 0.f);
+        }
+        c = 1.f / (1.f + expf(-c));                          // :361
+        if (fabsf(fx) > 1.f || fabsf(fy) > 1.f) c = 0.f;     // :368-370
+        fx = fminf(fmaxf(fx, -1.f), 1.f);                    // :371
+        fy = fminf(fmaxf(fy, -1.f), 1.f);
+        const float gx = gfn::linspace_at(lo, hi, G, j), gy = gfn::linspace_at(lo, hi, G, i);  // :362-367
+        const float4 w = second ? make_float4(fx, fy, gx, gy) : make_float4(gx, gy, fx, fy);   // :373-378
+        reinterpret_cast<float4 *>(warp)[idx] = w;
+        cert_out[idx] = c;
+    }
+}
+
+inline unsigned grid_for(long total, int cap = 16384) {
+    long g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+GFN_EXPORT int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w,
+                                     const float *disp_b, float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G,
+                                     int disp_dim, float disp_scale, gfn_stream_t stream) {
+    if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b)))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: null pointer");
+    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
+    if (B == 0) return GFN_OK;
+    const long total = (long)B * (2 * C + disp_dim) * G * G;
+    hipLaunchKernelGGL(refiner_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, f0, f1, flow, disp_w,
+                       disp_b, d, (long)d_bs, B, C, Hs, Ws, G, disp_dim, disp_scale);
+    return gfn::check_launch("refiner_input_kernel");
+}
+
+GFN_EXPORT int gfn_grid_sample_fwd(const float *in, const float *grid, float *out, int64_t out_bs, int B, int C, int H,
+                                   int W, int Ho, int Wo, gfn_stream_t stream) {
+    if (!in || !grid || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || out_bs < (int64_t)C * Ho * Wo)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "grid_sample: bad argument");
+    if (B == 0) return GFN_OK;
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(grid_for((long)B * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in,
+                       grid, out, (long)out_bs, B, C, H, W, Ho, Wo);
+    return gfn::check_launch("grid_sample_kernel");
+}
+
+GFN_EXPORT int gfn_interp_bilinear_fwd(const float *in, float *out, int BC, int H, int W, int Ho, int Wo,
+                                       gfn_stream_t stream) {
+    if (!in || !out || BC < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "interp_bilinear: bad argument");
+    if (BC == 0) return GFN_OK;
+    hipLaunchKernelGGL(interp_bilinear_kernel, dim3(grid_for((long)BC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, BC, H, W, Ho, Wo);
+    return gfn::check_launch("interp_bilinear_kernel");
+}
+
+GFN_EXPORT int gfn_flow_update_fwd(float *flow, float *certainty, const float *delta, int64_t delta_bs, float *disp_prev,
+                                   int B, int G, int scale, int W0, int H0, int zero_small, int first_iteration,
+                                   gfn_stream_t stream) {
+    if (!flow || !certainty || !delta || !disp_prev || B < 0 || G <= 0 || W0 <= 0 || H0 <= 0 || delta_bs < 3L * G * G)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "flow_update: bad argument");
+    if (B == 0) return GFN_OK;
+    hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((long)B * G * G)), dim3(256), 0, (hipStream_t)stream, flow,
+                       certainty, delta, (long)delta_bs, disp_prev, B, G, (float)scale, (float)(4 * W0), (float)(4 * H0),
+                       zero_small, first_iteration);
+    return gfn::check_launch("flow_update_kernel");
+}
+
+GFN_EXPORT int gfn_match_post_fwd(const float *flow, const float *certainty, const float *cert16_or_null, float *warp,
+                                  float *cert_out, int B_images, int G, int Gc, int symmetric, gfn_stream_t stream) {
+    if (!flow || !certainty || !warp || !cert_out || B_images < 0 || G <= 0 || (cert16_or_null && Gc <= 0))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "match_post: bad argument");
+    if (B_images == 0) return GFN_OK;
+    const long total = (long)B_images * G * (symmetric ? 2 * G : G);
+    hipLaunchKernelGGL(match_post_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, flow, certainty,
+                       cert16_or_null, warp, cert_out, B_images, G, Gc, symmetric);
+    return gfn::check_launch("match_post_kernel");
+}

@@ -1,0 +1,171 @@
+// kde.hip -- streaming Gaussian kernel density for gfx950.
+//
+// Replaces utils/kde.py:4-13 (called from GFNet.sample, model/network.py:408):
+//   density[n] = sum_m exp(-|x_n - y_m|^2 / (2 std^2)),   y = x[::down]
+// The reference materialises the N x M distance matrix through torch.cdist (1.6 GB in fp32 at
+// N = M = 20 000, or an fp16 matrix that is 12 % off); here nothing but the N sums is written.
+// The op is compute bound (N*M exponentials, 2*N*16 bytes of traffic): one thread per query,
+// the reference points y_m are wave-uniform (scalar loads / SGPR operands), two points per step
+// so that the subtract/multiply/fma chain packs into v_pk_*_f32, coordinates pre-scaled by
+// sqrt(log2(e)/(2 std^2)) so that the exponential is a bare v_exp_f32 (2^x).
+// Distances use the direct difference form (what cdist approximates with its |a|^2+|b|^2-2ab
+// matrix product); fp32 accumulation.  When N is too small to fill the chip the M range is split
+// over blockIdx.y and the partial sums are reduced by a second tiny kernel (deterministic, no
+// float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kKdeThreads = 256;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Pre-pass (D = 4): scale the coordinates once and lay the reference points out as pairs,
+// ys[bt][m/2][d][2], so that the main loop reads (a_d, c_d) of two points as one SGPR pair and
+// every arithmetic step is one packed v_pk_*_f32.  An odd tail is padded with a far-away point
+// (its term is exp2(-inf) = 0).
+__global__ __launch_bounds__(256) void kde4_prescale_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            float *__restrict__ xs, float *__restrict__ ys, int N,
+                                                            int M, long y_rs, long y_bs, float scale, int Bt) {
+    const int Mp = (M + 1) & ~1;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nx = (long)Bt * N * 4, ny = (long)Bt * Mp * 4;
+    if (idx < nx) xs[idx] = x[idx] * scale;
+    if (idx < ny) {
+        const int bt = (int)(idx / ((long)Mp * 4));
+        const long r = idx - (long)bt * Mp * 4;
+        const int pair = (int)(r >> 3), d = (int)((r >> 1) & 3), which = (int)(r & 1);
+        const int m = pair * 2 + which;
+        ys[idx] = (m < M) ? y[(size_t)bt * y_bs + (size_t)m * y_rs + d] * scale : 1e18f;
+    }
+}
+
+// xs: (Bt, N, 4) pre-scaled queries; ys: (Bt, Mp/2, 4, 2) pre-scaled point pairs;
+// part: (Bt, MS, N) partial sums (MS = gridDim.y) or the output itself when MS == 1.
+__global__ __launch_bounds__(kKdeThreads) void kde4_kernel(const float *__restrict__ xs, const float *__restrict__ ys,
+                                                           float *__restrict__ part, int N, int Mp) {
+    const int bt = blockIdx.z;
+    const int n = blockIdx.x * kKdeThreads + threadIdx.x;
+    const int MS = gridDim.y, ms = blockIdx.y;
+    const int npair = Mp >> 1;
+    const int per = (npair + MS - 1) / MS;
+    const int p0 = ms * per, p1 = min(npair, p0 + per);
+    const float4 xv = (n < N) ? reinterpret_cast<const float4 *>(xs)[(size_t)bt * N + n] : make_float4(0, 0, 0, 0);
+    const f32x2 x0 = {xv.x, xv.x}, x1 = {xv.y, xv.y}, x2 = {xv.z, xv.z}, x3 = {xv.w, xv.w};
+    const f32x2 *yp = reinterpret_cast<const f32x2 *>(ys) + (size_t)bt * npair * 4;
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) {
+        // wave-uniform address -> scalar loads; each operand below is an SGPR pair
+        const f32x2 d0 = x0 - yp[(size_t)p * 4 + 0];
+        const f32x2 d1 = x1 - yp[(size_t)p * 4 + 1];
+        const f32x2 d2 = x2 - yp[(size_t)p * 4 + 2];
+        const f32x2 d3 = x3 - yp[(size_t)p * 4 + 3];
+        f32x2 sq = d0 * d0;
+        sq = __builtin_elementwise_fma(d1, d1, sq);
+        sq = __builtin_elementwise_fma(d2, d2, sq);
+        sq = __builtin_elementwise_fma(d3, d3, sq);
+        f32x2 e;
+        e.x = __builtin_amdgcn_exp2f(-sq.x);
+        e.y = __builtin_amdgcn_exp2f(-sq.y);
+        acc += e;
+    }
+    if (n < N) part[((size_t)bt * MS + ms) * N + n] = acc.x + acc.y;
+}
+
+// any point dimension D (the reference never uses anything but 4)
+__global__ __launch_bounds__(kKdeThreads) void kde_generic_kernel(const float *__restrict__ x,
+                                                                  const float *__restrict__ y, float *__restrict__ part,
+                                                                  int N, int M, int D, long y_rs, long y_bs,
+                                                                  float scale) {
+    const int bt = blockIdx.z;
+    const int n = blockIdx.x * kKdeThreads + threadIdx.x;
+    const int MS = gridDim.y, ms = blockIdx.y;
+    const int per = (M + MS - 1) / MS;
+    const int m0 = ms * per, m1 = min(M, m0 + per);
+    if (n >= N) return;
+    const float *xn = x + ((size_t)bt * N + n) * D;
+    const float *yb = y + (size_t)bt * y_bs;
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float t = (xn[d] - yb[(size_t)m * y_rs + d]) * scale;
+            s = fmaf(t, t, s);
+        }
+        acc += __builtin_amdgcn_exp2f(-s);
+    }
+    part[((size_t)bt * MS + ms) * N + n] = acc;
+}
+
+__global__ __launch_bounds__(256) void kde_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int N,
+                                                         int MS, int Bt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Bt * N) return;
+    const int bt = (int)(idx / N), n = (int)(idx - (long)bt * N);
+    float s = 0.f;
+    for (int k = 0; k < MS; ++k) s += part[((size_t)bt * MS + k) * N + n];  // fixed order: reproducible
+    out[idx] = s;
+}
+
+}  // namespace
+
+GFN_EXPORT int gfn_kde_msplit(int Bt, int N, int M) {
+    // enough blocks to fill 256 CUs x 8, but keep >= 512 reference points per split
+    const long blocks = (long)Bt * ((N + kKdeThreads - 1) / kKdeThreads);
+    int ms = 1;
+    while (blocks * ms < 2048 && M / (ms * 2) >= 512) ms *= 2;
+    return ms;
+}
+
+// Scratch floats gfn_kde_density wants for (Bt, N, M, D): the pre-scaled copies (D == 4) plus the
+// split-M partial sums.  With less scratch the call still works (single pass / generic kernel).
+GFN_EXPORT int64_t gfn_kde_scratch_floats(int Bt, int N, int M, int D) {
+    const int MS = gfn_kde_msplit(Bt, N, M);
+    int64_t n = MS > 1 ? (int64_t)Bt * MS * N : 0;
+    if (D == 4) n += (int64_t)Bt * N * 4 + (int64_t)Bt * ((M + 1) & ~1) * 4;
+    return n;
+}
+
+GFN_EXPORT int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, int M, int D,
+                               int64_t y_row_stride, int64_t y_batch_stride, double std, float *scratch,
+                               int64_t scratch_floats, gfn_stream_t stream) {
+    if (!x || !y || !out) return gfn::fail(GFN_ERR_INVALID_ARG, "kde: null pointer");
+    if (Bt < 0 || N < 0 || M < 0 || D <= 0 || y_row_stride < D || !(std > 0))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "kde: bad argument Bt=%d N=%d M=%d D=%d std=%g", Bt, N, M, D, std);
+    if (Bt > 65535) return gfn::fail(GFN_ERR_INVALID_ARG, "kde: batch > 65535");
+    if (Bt == 0 || N == 0) return GFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)Bt * N, s);
+        return e == hipSuccess ? GFN_OK : gfn::fail(GFN_ERR_LAUNCH, "kde: memset failed");
+    }
+    if (!scratch) scratch_floats = 0;
+    // exp(-d^2/(2 std^2)) = 2^(-(d*scale)^2),  scale = sqrt(log2(e) / (2 std^2))
+    const float scale = (float)sqrt(1.4426950408889634 / (2.0 * std * std));
+    const int Mp = (M + 1) & ~1;
+    const int64_t pre = (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4;
+    const bool fast = D == 4 && scratch_floats >= pre && ((uintptr_t)scratch % 16) == 0;
+    int64_t left = scratch_floats - (fast ? pre : 0);
+    float *pscratch = scratch + (fast ? pre : 0);
+    int MS = gfn_kde_msplit(Bt, N, M);
+    if (MS > 1 && left < (int64_t)Bt * MS * N) MS = 1;  // no room for partials: single pass
+    float *part = MS > 1 ? pscratch : out;
+    const dim3 grid((N + kKdeThreads - 1) / kKdeThreads, MS, Bt);
+    if (fast) {
+        float *xs = scratch, *ys = scratch + (int64_t)Bt * N * 4;
+        const long tot = (long)Bt * 4 * (N > Mp ? N : Mp);
+        hipLaunchKernelGGL(kde4_prescale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, y, xs, ys, N, M,
+                           (long)y_row_stride, (long)y_batch_stride, scale, Bt);
+        hipLaunchKernelGGL(kde4_kernel, grid, dim3(kKdeThreads), 0, s, xs, ys, part, N, Mp);
+    } else {
+        hipLaunchKernelGGL(kde_generic_kernel, grid, dim3(kKdeThreads), 0, s, x, y, part, N, M, D, (long)y_row_stride,
+                           (long)y_batch_stride, scale);
+    }
+    if (int e = gfn::check_launch("kde_kernel")) return e;
+    if (MS > 1) {
+        const long total = (long)Bt * N;
+        hipLaunchKernelGGL(kde_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, out, N, MS, Bt);
+        return gfn::check_launch("kde_reduce_kernel");
+    }
+    return GFN_OK;
+}

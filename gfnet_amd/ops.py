@@ -1,0 +1,206 @@
+"""Thin Python bindings of the C-ABI entry points (include/gfnet_hip.h) on torch device tensors.
+
+Each function cites the reference code it stands in for (paths relative to KN-Zhang/GFNet).
+torch supplies device memory and the current HIP stream; every result comes from csrc/*.hip.
+There is no CPU implementation here: CPU tensors raise.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import c_vp, check, f32c, ptr, require_gpu, stream_ptr
+
+
+def _L():
+    return _lib.lib()
+
+
+def corr_softargmax(feat0, feat1):
+    """pos_embed(corr_volume(feat0, feat1)) without writing the volume (model/network.py:251-252, 415-440).
+    feat0 (B,C,H0,W0), feat1 (B,C,H1,W1) -> flow (B,2,H0,W0)."""
+    dev = require_gpu(feat0, feat1)
+    f0, f1 = f32c(feat0), f32c(feat1)
+    B, C, H0, W0 = f0.shape
+    B1, C1, H1, W1 = f1.shape
+    if B1 != B or C1 != C:
+        raise ValueError("feat0/feat1 batch or channel mismatch")
+    flow = torch.empty((B, 2, H0, W0), device=dev, dtype=torch.float32)
+    check(_L().gfn_corr_softargmax_fwd(ptr(f0), ptr(f1), ptr(flow), B, C, H0, W0, H1, W1, stream_ptr(dev)),
+          "gfn_corr_softargmax_fwd")
+    return flow
+
+
+def corr_volume(feat0, feat1, with_flow=False):
+    """GFNet.corr_volume (model/network.py:415-428): (B,H1,W1,H0,W0) = f0^T f1 / sqrt(C)."""
+    dev = require_gpu(feat0, feat1)
+    f0, f1 = f32c(feat0), f32c(feat1)
+    B, C, H0, W0 = f0.shape
+    _, _, H1, W1 = f1.shape
+    vol = torch.empty((B, H1, W1, H0, W0), device=dev, dtype=torch.float32)
+    flow = torch.empty((B, 2, H0, W0), device=dev, dtype=torch.float32) if with_flow else None
+    check(_L().gfn_corr_volume_fwd(ptr(f0), ptr(f1), ptr(vol), ptr(flow), B, C, H0, W0, H1, W1, stream_ptr(dev)),
+          "gfn_corr_volume_fwd")
+    return (vol, flow) if with_flow else vol
+
+
+def pos_embed(corr_vol):
+    """GFNet.pos_embed (model/network.py:430-440) on an explicit volume (B,H1,W1,H0,W0) -> (B,2,H0,W0)."""
+    dev = require_gpu(corr_vol)
+    v = f32c(corr_vol)
+    B, H1, W1, H0, W0 = v.shape
+    flow = torch.empty((B, 2, H0, W0), device=dev, dtype=torch.float32)
+    check(_L().gfn_pos_embed_fwd(ptr(v), ptr(flow), B, H0, W0, H1, W1, stream_ptr(dev)), "gfn_pos_embed_fwd")
+    return flow
+
+
+def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_factor=1.0, corr_in_other=True):
+    """The concat tensor `d` of ConvRefiner.forward (model/network.py:533-558):
+    cat(grid_sample(x, cell centres), grid_sample(y, flow), disp_emb(40/32*scale_factor*(flow-centres)),
+    local_correlation(...)) -- every slice written in place by the HIP kernels, no torch.cat."""
+    dev = require_gpu(x, y, flow, disp_w, disp_b)
+    x, y, fl = f32c(x), f32c(y), f32c(flow)
+    B, C, Hs, Ws = x.shape
+    G = int(num_grid)
+    w = f32c(disp_w).reshape(-1, 2)
+    bvec = f32c(disp_b).reshape(-1)
+    Dd = w.shape[0]
+    r = int(local_radius)
+    K = (2 * r + 1) ** 2 if corr_in_other else 0
+    CH = 2 * C + Dd + K
+    d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
+    st = stream_ptr(dev)
+    check(_L().gfn_refiner_input_fwd(ptr(x), ptr(y), ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
+                                     float(40 / 32 * scale_factor), st), "gfn_refiner_input_fwd")
+    if corr_in_other:
+        out = d[:, 2 * C + Dd:]
+        check(_L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(fl), c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs,
+                                      Ws, r, 0, Hs, Ws, st), "gfn_local_corr_fwd")
+    return d
+
+
+def grid_sample(x, grid):
+    """F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=False)."""
+    dev = require_gpu(x, grid)
+    x, g = f32c(x), f32c(grid)
+    B, C, H, W = x.shape
+    _, Ho, Wo, _ = g.shape
+    out = torch.empty((B, C, Ho, Wo), device=dev, dtype=torch.float32)
+    check(_L().gfn_grid_sample_fwd(ptr(x), ptr(g), ptr(out), C * Ho * Wo, B, C, H, W, Ho, Wo, stream_ptr(dev)),
+          "gfn_grid_sample_fwd")
+    return out
+
+
+def interpolate_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) (model/network.py:238-249,271-281)."""
+    dev = require_gpu(x)
+    x = f32c(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    out = torch.empty((B, C, Ho, Wo), device=dev, dtype=torch.float32)
+    check(_L().gfn_interp_bilinear_fwd(ptr(x), ptr(out), B * C, H, W, Ho, Wo, stream_ptr(dev)), "gfn_interp_bilinear_fwd")
+    return out
+
+
+def flow_update_(flow, certainty, delta, disp_prev, scale, W0, H0, zero_small=True, first_iteration=True):
+    """In place: model/network.py:262-268.  delta is the refiner output (B,3,G,G) (channels 0,1 =
+    displacement, 2 = certainty increment); disp_prev (B,2,G,G) carries the previous displacement."""
+    dev = require_gpu(flow, certainty, delta, disp_prev)
+    B, _, G, _ = flow.shape
+    for t in (flow, certainty, disp_prev):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("flow_update_: flow/certainty/disp_prev must be contiguous fp32 (updated in place)")
+    dl = f32c(delta)
+    check(_L().gfn_flow_update_fwd(ptr(flow), ptr(certainty), ptr(dl), dl.shape[1] * G * G, ptr(disp_prev), B, G, int(scale),
+                                   int(W0), int(H0), 1 if zero_small else 0, 1 if first_iteration else 0, stream_ptr(dev)),
+          "gfn_flow_update_fwd")
+    return flow, certainty
+
+
+def match_post(flow, certainty, cert16=None, symmetric=True):
+    """model/network.py:332-338 + 358-384: returns warp (B,G,2G,4)/(B,G,G,4) and certainty (B,G,2G)/(B,G,G)."""
+    dev = require_gpu(flow, certainty, cert16)
+    fl, ce = f32c(flow), f32c(certainty)
+    nb, _, G, _ = fl.shape
+    B = nb // 2 if symmetric else nb
+    Gw = 2 * G if symmetric else G
+    c16 = f32c(cert16) if cert16 is not None else None
+    Gc = c16.shape[-1] if c16 is not None else 0
+    warp = torch.empty((B, G, Gw, 4), device=dev, dtype=torch.float32)
+    cout = torch.empty((B, G, Gw), device=dev, dtype=torch.float32)
+    check(_L().gfn_match_post_fwd(ptr(fl), ptr(ce), ptr(c16), ptr(warp), ptr(cout), B, G, Gc, 1 if symmetric else 0,
+                                  stream_ptr(dev)), "gfn_match_post_fwd")
+    return warp, cout
+
+
+def kde_density(x, y=None, std=0.1, y_row_stride=None):
+    """sum_m exp(-|x_n - y_m|^2/(2 std^2)); x (N,D) or (Bt,N,D); y defaults to x.  fp32."""
+    dev = require_gpu(x, y)
+    xs = f32c(x)
+    squeeze = xs.dim() == 2
+    if squeeze:
+        xs = xs[None]
+    Bt, N, D = xs.shape
+    if y is None:
+        ys, M, rs, bs = xs, N, D, N * D
+    else:
+        ys = f32c(y)
+        if ys.dim() == 2:
+            ys = ys[None]
+        M, rs, bs = ys.shape[1], D, ys.shape[1] * D
+    if y_row_stride is not None:  # strided view of ys (x[::down]) without a copy
+        rs = int(y_row_stride)
+        M = (ys.shape[1] * D + rs - 1) // rs
+    out = torch.empty((Bt, N), device=dev, dtype=torch.float32)
+    nscr = int(_L().gfn_kde_scratch_floats(Bt, N, M, D))
+    scratch = torch.empty((max(nscr, 4),), device=dev, dtype=torch.float32)
+    check(_L().gfn_kde_density(ptr(xs), ptr(ys), ptr(out), Bt, N, M, D, rs, bs, float(std), ptr(scratch), nscr,
+                               stream_ptr(dev)), "gfn_kde_density")
+    return out[0] if squeeze else out
+
+
+def convert_matches(matches, wA, hA, wB, hB):
+    """estimation.py:26-45 on the device: (...,4) normalised warp rows -> pixel (x,y,u,v), float32."""
+    dev = require_gpu(matches)
+    m = f32c(matches)
+    out = torch.empty_like(m)
+    n = m.numel() // 4
+    check(_L().gfn_convert_matches(ptr(m), ptr(out), n, float(wA), float(hA), float(wB), float(hB), stream_ptr(dev)),
+          "gfn_convert_matches")
+    return out
+
+
+def find_homography(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False):
+    """Batched stand-in for cv2.findHomography(pos_a, pos_b, cv2.RANSAC, ransacReprojThreshold=thresh)
+    (estimation.py:66-72), on the device.  pts (Bt,N,4) or (N,4) pixel (x,y,u,v).
+    Returns H (Bt,3,3) float64, inlier counts (Bt,), chosen hypothesis index (Bt,) [, mask (Bt,N) uint8]."""
+    dev = require_gpu(pts)
+    p = f32c(pts)
+    if p.dim() == 2:
+        p = p[None]
+    Bt, N, _ = p.shape
+    H = torch.empty((Bt, 3, 3), device=dev, dtype=torch.float64)
+    ninl = torch.empty((Bt,), device=dev, dtype=torch.int32)
+    best = torch.empty((Bt,), device=dev, dtype=torch.int32)
+    mask = torch.empty((Bt, N), device=dev, dtype=torch.uint8) if return_mask else None
+    nb = int(_L().gfn_homography_scratch_bytes(Bt, int(iters)))
+    scratch = torch.empty((nb // 8 + 1,), device=dev, dtype=torch.float64)
+    check(_L().gfn_homography_ransac(ptr(p), Bt, N, float(thresh), int(iters), int(seed), int(lm_iters), int(stage), ptr(H),
+                                     ptr(ninl), ptr(best), ptr(mask), ptr(scratch), nb, stream_ptr(dev)),
+          "gfn_homography_ransac")
+    return (H, ninl, best, mask) if return_mask else (H, ninl, best)
+
+
+def homography_dlt(pts, weight=None):
+    """One-shot weighted normalised DLT over all correspondences ("grid-DLT").  pts (Bt,N,4) pixels,
+    weight (Bt,N) or None -> H (Bt,3,3) float64, ok (Bt,) int32."""
+    dev = require_gpu(pts, weight)
+    p = f32c(pts)
+    if p.dim() == 2:
+        p = p[None]
+    Bt, N, _ = p.shape
+    w = f32c(weight).reshape(Bt, N) if weight is not None else None
+    H = torch.empty((Bt, 3, 3), device=dev, dtype=torch.float64)
+    ok = torch.empty((Bt,), device=dev, dtype=torch.int32)
+    check(_L().gfn_homography_dlt(ptr(p), ptr(w), Bt, N, ptr(H), ptr(ok), stream_ptr(dev)), "gfn_homography_dlt")
+    return H, ok

@@ -78,6 +78,96 @@ int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const
  * in (BC,H,W) -> out (BC,H/2,W/2). */
 int gfn_avg_pool2(const float *in, float *out, int BC, int H, int W, gfn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Global correlation + soft-argmax -- model/network.py:415-428 (GFNet.corr_volume) and :430-440
+ * (GFNet.pos_embed), called at :251-252.
+ *   V[b,j,i]     = sum_c f0[b,c,i] * f1[b,c,j] / sqrt(C)        vol: (B,H1,W1,H0,W0)
+ *   flow[b,:,i]  = sum_j softmax_j(V[b,j,i]) * (x_j, y_j)        flow: (B,2,H0,W0)
+ * gfn_corr_softargmax_fwd is the fused form (the volume is never written);
+ * gfn_corr_volume_fwd writes the volume (and the flow too when flow_or_null != NULL);
+ * gfn_pos_embed_fwd is pos_embed on a caller-supplied volume.  f0 (B,C,H0,W0), f1 (B,C,H1,W1),
+ * C <= 128.
+ */
+int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B, int C, int H0, int W0, int H1, int W1,
+                            gfn_stream_t stream);
+int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C, int H0, int W0,
+                        int H1, int W1, gfn_stream_t stream);
+int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1, gfn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ConvRefiner.forward prefix -- model/network.py:533-555.  Writes, into the concat buffer
+ * d (B, 2C+disp_dim[+K], G, G) with batch stride d_bs:
+ *   d[:, 0:C]          = grid_sample(f0, cell centres)                    (:539-547)
+ *   d[:, C:2C]         = grid_sample(f1, flow)                            (:537)
+ *   d[:, 2C:2C+disp]   = disp_w @ (disp_scale * (flow - centres)) + disp_b (:548-549),
+ *                        disp_scale = 40/32 * scale_factor, disp_w (disp_dim,2), disp_b (disp_dim)
+ * The local-correlation slice d[:, 2C+disp:] is filled by gfn_local_corr_fwd with
+ * f0 = d (batch stride d_bs) and out = d + (2C+disp)*G*G (batch stride d_bs).
+ */
+int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w, const float *disp_b,
+                          float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
+                          gfn_stream_t stream);
+
+/* F.grid_sample(in, grid, mode='bilinear', padding_mode='zeros', align_corners=False):
+ * in (B,C,H,W), grid (B,Ho,Wo,2) -> out (B,C,Ho,Wo) with batch stride out_bs. */
+int gfn_grid_sample_fwd(const float *in, const float *grid, float *out, int64_t out_bs, int B, int C, int H, int W,
+                        int Ho, int Wo, gfn_stream_t stream);
+
+/* F.interpolate(x, size=(Ho,Wo), mode='bilinear', align_corners=False) -- model/network.py:238-249,
+ * 271-281, 333-335.  in (BC,H,W) -> out (BC,Ho,Wo). */
+int gfn_interp_bilinear_fwd(const float *in, float *out, int BC, int H, int W, int Ho, int Wo, gfn_stream_t stream);
+
+/* Flow/certainty accumulation of one refiner iteration -- model/network.py:262-268, in place:
+ *   disp = scale * (delta[:,0]/(4*W0), delta[:,1]/(4*H0)); eval mode (zero_small): components with
+ *   |disp - disp_prev| / |disp_prev| < 1e-6 are zeroed (disp_prev = 1e-7 when first_iteration);
+ *   flow += disp; certainty += delta[:,2]; disp_prev <- disp.
+ * flow (B,2,G,G), certainty (B,1,G,G), delta (B,>=3,G,G) with batch stride delta_bs, disp_prev (B,2,G,G). */
+int gfn_flow_update_fwd(float *flow, float *certainty, const float *delta, int64_t delta_bs, float *disp_prev, int B, int G,
+                        int scale, int W0, int H0, int zero_small, int first_iteration, gfn_stream_t stream);
+
+/* match() post-processing -- model/network.py:332-338 + 358-384.
+ *   flow (nb,2,G,G), certainty (nb,1,G,G) finest-scale logits, nb = 2*B_images when symmetric;
+ *   cert16_or_null (nb,1,Gc,Gc): scale-16 certainty for the attenuation term, or NULL;
+ *   warp (B_images, G, Gw, 4), cert_out (B_images, G, Gw), Gw = 2G (symmetric) or G. */
+int gfn_match_post_fwd(const float *flow, const float *certainty, const float *cert16_or_null, float *warp, float *cert_out,
+                       int B_images, int G, int Gc, int symmetric, gfn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gaussian KDE -- utils/kde.py:4-13 (called from GFNet.sample, model/network.py:408).
+ *   out[bt,n] = sum_m exp(-|x[bt,n] - y[bt,m]|^2 / (2 std^2))
+ * x (Bt,N,D) contiguous; y: Bt blocks of M rows, row stride y_row_stride floats (= down*D for
+ * x[::down]), batch stride y_batch_stride floats; out (Bt,N).  scratch: optional device buffer of
+ * gfn_kde_scratch_floats(...) floats (pre-scaled copies + split-M partial sums); with less the
+ * call falls back to a slower single-pass kernel but stays correct.
+ */
+int gfn_kde_msplit(int Bt, int N, int M);
+int64_t gfn_kde_scratch_floats(int Bt, int N, int M, int D);
+int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, int M, int D, int64_t y_row_stride,
+                    int64_t y_batch_stride, double std, float *scratch, int64_t scratch_floats, gfn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Homography solve -- estimation.py:60-77 (cv2.findHomography(..., cv2.RANSAC, confidence=0.99999,
+ * ransacReprojThreshold=3) in the reference; OpenCV's published pipeline restated, see
+ * oracle/homography_oracle.c) and estimation.py:26-45 (convert_coordinates).
+ *
+ * gfn_convert_matches: matches (n,4) normalised warp rows -> pts (n,4) pixel (x,y,u,v), float32,
+ *   (w-1)*(x+1)/2 per coordinate.
+ * gfn_homography_ransac: pts (Bt,N,4) pixels -> H (Bt,9) row-major double (H[8] = 1),
+ *   ninl (Bt) inlier count of the chosen hypothesis, best_t (Bt) its index or -1,
+ *   mask (Bt,N) bytes or NULL.  Failure (fewer than 4 inliers / degenerate) gives diag(0,0,1),
+ *   the reference's convention (estimation.py:74-76).  stage: 0 = RANSAC -> DLT on inliers ->
+ *   lm_iters LM steps; 1 = RANSAC only; 2 = RANSAC + DLT.  scratch: gfn_homography_scratch_bytes().
+ * gfn_homography_dlt: one-shot weighted normalised DLT ("grid-DLT"): weight (Bt,N) float or NULL;
+ *   ok (Bt) = 1 on success.
+ */
+int gfn_convert_matches(const float *matches, float *pts, int64_t n, float wA, float hA, float wB, float hB,
+                        gfn_stream_t stream);
+int64_t gfn_homography_scratch_bytes(int Bt, int iters);
+int gfn_homography_ransac(const float *pts, int Bt, int N, double thresh, int iters, uint64_t seed, int lm_iters, int stage,
+                          double *H, int *ninl, int *best_t, unsigned char *mask, void *scratch, int64_t scratch_bytes,
+                          gfn_stream_t stream);
+int gfn_homography_dlt(const float *pts, const float *weight, int Bt, int N, double *H, int *ok, gfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

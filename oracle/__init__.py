@@ -309,3 +309,63 @@ def auc(errors, thresholds):
         e = np.r_[errors[:last], t]
         out.append(float(np.sum((e[1:] - e[:-1]) * (r[1:] + r[:-1]) / 2) / t))
     return out
+
+
+# ---- homography solve (estimation.py:60-77; OpenCV pipeline restated -- parity with OpenCV unpinned) ----
+def convert_matches(matches, wA, hA, wB, hB):
+    """estimation.py:26-45 in float32 (numpy's own evaluation order): (N,4) normalised -> (N,4) pixels."""
+    m = np.ascontiguousarray(matches, np.float32).reshape(-1, 4)
+    pts = np.empty_like(m)
+    lib("f64").oracle_convert_matches(_p(m), _p(pts), _c_long(m.shape[0]), ctypes.c_float(wA), ctypes.c_float(hA),
+                                      ctypes.c_float(wB), ctypes.c_float(hB))
+    return pts.reshape(np.shape(matches))
+
+
+def homography_dlt(pts, weight=None):
+    """Weighted normalised DLT ("grid-DLT"): pts (Bt,N,4) pixel (x,y,u,v) -> H (Bt,3,3), ok (Bt,)."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    Bt, N, _ = pts.shape
+    w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+    H = np.empty((Bt, 9), np.float64)
+    ok = np.empty((Bt,), np.int32)
+    lib("f64").oracle_homography_dlt(_p(pts), _p(w), _c_int(Bt), _c_int(N), _p(H), _p(ok))
+    return H.reshape(Bt, 3, 3), ok
+
+
+def homography_ransac(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False):
+    """RANSAC(4-pt) -> DLT on inliers -> LM (the findHomography pipeline).  pts (Bt,N,4) pixels.
+    Returns H (Bt,3,3), inlier counts (Bt,), chosen hypothesis (Bt,) [, mask (Bt,N)]."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    Bt, N, _ = pts.shape
+    H = np.empty((Bt, 9), np.float64)
+    ninl = np.empty((Bt,), np.int32)
+    best = np.empty((Bt,), np.int32)
+    mask = np.empty((Bt, N), np.uint8) if return_mask else None
+    lib("f64").oracle_homography_ransac(_p(pts), _c_int(Bt), _c_int(N), ctypes.c_double(thresh), _c_int(iters),
+                                        ctypes.c_uint64(seed), _c_int(lm_iters), _c_int(stage), _p(H), _p(ninl), _p(best),
+                                        _p(mask))
+    out = (H.reshape(Bt, 3, 3), ninl, best)
+    return out + (mask,) if return_mask else out
+
+
+def homography_dlt_svd(pts, weight=None):
+    """Independent float64 numpy-SVD DLT with Hartley normalisation (cross-check for the tests)."""
+    pts = np.asarray(pts, np.float64)
+    w = np.ones(len(pts)) if weight is None else np.asarray(weight, np.float64)
+
+    def norm(p):
+        c = (w[:, None] * p).sum(0) / w.sum()
+        s = np.sqrt(2) / ((w * np.linalg.norm(p - c, axis=1)).sum() / w.sum())
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1]])
+        return (p - c) * s, T
+
+    a, Ta = norm(pts[:, :2])
+    b, Tb = norm(pts[:, 2:])
+    sw = np.sqrt(w)
+    rows = []
+    for (x, y), (u, v), s in zip(a, b, sw):
+        rows.append(s * np.array([x, y, 1, 0, 0, 0, -u * x, -u * y, -u]))
+        rows.append(s * np.array([0, 0, 0, x, y, 1, -v * x, -v * y, -v]))
+    _, _, Vt = np.linalg.svd(np.array(rows))
+    H = np.linalg.inv(Tb) @ Vt[-1].reshape(3, 3) @ Ta
+    return H / H[2, 2]

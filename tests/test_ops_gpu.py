@@ -1,0 +1,246 @@
+"""GPU parity of the remaining hot-path kernels (through the C ABI) against the oracle and the
+reference-generated goldens.  Tolerances: 1e-4 abs+rel for correlation/flow tensors (north_star);
+H within 1e-3 px corner error of the oracle on identical matches."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+# ---- A2/A3 corr_volume + pos_embed ------------------------------------------------------------
+def test_g2_golden_volume_flow():
+    from gfnet_amd import ops
+
+    g = load_golden("g2_corr_softargmax")
+    assert_close(host(ops.corr_softargmax(dev(g["f0"]), dev(g["f1"]))), g["flow"], TOL, "fused flow")
+    vol, flow = ops.corr_volume(dev(g["f0"]), dev(g["f1"]), with_flow=True)
+    assert_close(host(vol), g["vol"], TOL, "vol")
+    assert_close(host(flow), g["flow"], TOL, "flow with vol")
+    assert_close(host(ops.corr_volume(dev(g["f0"]), dev(g["f1"]))), g["vol"], TOL, "vol only")
+    assert_close(host(ops.pos_embed(dev(g["vol"]))), g["flow"], TOL, "pos_embed")
+    # rectangular, A and B of different size, 35 / 24 positions (not multiples of 32)
+    assert_close(host(ops.corr_softargmax(dev(g["f0_rect"]), dev(g["f1_rect"]))), g["flow_rect"], TOL, "rect flow")
+    assert_close(host(ops.corr_volume(dev(g["f0_rect"]), dev(g["f1_rect"]))), g["vol_rect"], TOL, "rect vol")
+
+
+def test_g2_golden_production_shape():
+    from gfnet_amd import ops
+
+    g = load_golden("g2_corr_softargmax")
+    s0, s1 = [int(v) for v in g["prod_seeds"]]
+    f0 = 3 * synth.lattice_normalish((1, 64, 32, 32), s0)
+    f1 = 3 * synth.lattice_normalish((1, 64, 32, 32), s1)
+    assert_close(host(ops.corr_softargmax(dev(f0), dev(f1))), g["flow_prod"], TOL, "flow prod")
+
+
+@pytest.mark.parametrize("C,H0,H1,B", [(64, 48, 48, 2), (64, 32, 32, 3), (16, 12, 20, 2), (7, 9, 5, 1)])
+def test_corr_softargmax_vs_oracle(C, H0, H1, B):
+    from gfnet_amd import ops
+
+    f0 = 2 * synth.lattice_normalish((B, C, H0, H0), 71)
+    f1 = 2 * synth.lattice_normalish((B, C, H1, H1 + 1), 72)
+    assert_close(host(ops.corr_softargmax(dev(f0), dev(f1))), oracle.corr_softargmax(f0, f1), TOL, "flow")
+
+
+# ---- A8 kde -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [512, 4096])
+def test_g3_golden_kde(N):
+    from gfnet_amd.utils.kde import kde
+
+    g = load_golden("g3_kde")
+    x = dev(g[f"x_{N}"])
+    np.testing.assert_allclose(host(kde(x, 0.1, half=False, down=None)), g[f"density_{N}_full"], rtol=2e-4)
+    np.testing.assert_allclose(host(kde(x, 0.1, half=False, down=8)), g[f"density_{N}_down8"], rtol=2e-4)
+    np.testing.assert_allclose(host(kde(x, 0.1, half=False, down=1)), g[f"density_{N}_down1"], rtol=2e-4)
+    np.testing.assert_allclose(host(kde(x, 0.1, half=False)), g[f"density_{N}_exact64"], rtol=1e-4)
+    h = kde(x, 0.1, half=True)
+    assert h.dtype == torch.float16
+    np.testing.assert_allclose(host(h.float()), oracle.kde(g[f"x_{N}"], 0.1, half=True), rtol=2e-3)
+
+
+def test_kde_std_down_odd_sizes_and_batch():
+    from gfnet_amd import ops
+    from gfnet_amd.utils.kde import kde
+
+    g = load_golden("g3_kde")
+    np.testing.assert_allclose(host(kde(dev(g["x_std"]), 0.25, half=False, down=3)), g["density_std0.25"], rtol=2e-4)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(3, 777, 4)).astype(np.float32)
+    out = host(ops.kde_density(dev(x), std=0.15))
+    for b in range(3):
+        np.testing.assert_allclose(out[b], oracle.kde(x[b], 0.15, half=False), rtol=1e-4)
+    x5 = rng.uniform(-1, 1, size=(300, 5)).astype(np.float32)  # generic point dimension
+    np.testing.assert_allclose(host(ops.kde_density(dev(x5), std=0.3)), oracle.kde(x5, 0.3, half=False), rtol=1e-4)
+
+
+def test_kde_full_size_matches_oracle():
+    from gfnet_amd.utils.kde import kde
+
+    rng = np.random.default_rng(1)
+    centers = rng.uniform(-1, 1, size=(16, 4))
+    x = (centers[rng.integers(0, 16, 20000)] + 0.05 * rng.standard_normal((20000, 4))).astype(np.float32)
+    got = host(kde(dev(x), 0.1, half=False, down=None))
+    np.testing.assert_allclose(got, oracle.kde(x, 0.1, half=False), rtol=1e-4)
+
+
+# ---- A4 refiner input, grid_sample, interpolate ---------------------------------------------------
+def test_g4_golden_refiner_input():
+    from gfnet_amd import ops
+
+    g = load_golden("g4_refiner_prefix")
+    d = ops.refiner_input(int(g["G"]), dev(g["x"]), dev(g["y"]), dev(g["flow"]), dev(g["sd.disp_emb.weight"]),
+                          dev(g["sd.disp_emb.bias"]), int(g["r"]), scale_factor=float(g["scale_factor"]))
+    assert_close(host(d), g["d"], TOL, "d")
+    d1 = ops.refiner_input(int(g["G"]), dev(g["x"]), dev(g["y"]), dev(g["flow"]), dev(g["sd1.disp_emb.weight"]),
+                           dev(g["sd1.disp_emb.bias"]), 0, scale_factor=1.0, corr_in_other=False)
+    assert_close(host(d1), g["d_nocorr"], TOL, "d (no corr)")
+
+
+def test_refiner_input_production_shape_vs_oracle():
+    from gfnet_amd import ops
+
+    B, c, hs, G, r, Dd = 2, 32, 112, 64, 4, 32
+    x = synth.lattice_normalish((B, c, hs, hs), 81)
+    y = synth.lattice_normalish((B, c, hs, hs), 82)
+    flow = synth.homography_flow(B, G, 83)
+    w = synth.lattice_uniform((Dd, 2, 1, 1), 84)
+    bias = synth.lattice_uniform((Dd,), 85)
+    d = ops.refiner_input(G, dev(x), dev(y), dev(flow), dev(w), dev(bias), r, scale_factor=1.25)
+    assert_close(host(d), oracle.refiner_input(G, x, y, flow, w, bias, r, scale_factor=1.25), TOL, "d")
+
+
+def test_grid_sample_and_interpolate_vs_oracle():
+    from gfnet_amd import ops
+
+    x = synth.lattice_normalish((2, 5, 13, 17), 91)
+    grid = 1.3 * synth.lattice_uniform((2, 7, 9, 2), 92)
+    assert_close(host(ops.grid_sample(dev(x), dev(grid))), oracle.grid_sample(x, grid), 1e-5, "grid_sample")
+    for size in [(5, 5), (26, 34), (13, 17), (40, 3)]:
+        assert_close(host(ops.interpolate_bilinear(dev(x), size)), oracle.interpolate_bilinear(x, size), 1e-6,
+                     f"interp {size}")
+    g5 = load_golden("g5_forward_loop")  # flow upsampling between scales on reference data
+    f = g5["flow.2.1"]
+    assert_close(host(ops.interpolate_bilinear(dev(f), 32)), oracle.interpolate_bilinear(f, 32), 1e-6, "flow up")
+
+
+# ---- A5 flow update, A6 match post ------------------------------------------------------------------
+def test_flow_update_vs_oracle():
+    from gfnet_amd import ops
+
+    B, G = 2, 12
+    flow = synth.lattice_uniform((B, 2, G, G), 101)
+    cert = synth.lattice_uniform((B, 1, G, G), 102)
+    delta = 3 * synth.lattice_uniform((B, 3, G, G), 103)
+    prev0 = np.full((B, 2, G, G), 1e-7, np.float32)
+    f1, c1, d1 = oracle.flow_update(flow, cert, delta[:, :2], delta[:, 2:3], prev0, 8, 448, 448)
+    tf, tc, tp = dev(flow), dev(cert), torch.zeros(B, 2, G, G, device="cuda")
+    ops.flow_update_(tf, tc, dev(delta), tp, 8, 448, 448, zero_small=True, first_iteration=True)
+    assert_close(host(tf), f1, 1e-6, "flow")
+    assert_close(host(tc), c1, 1e-6, "cert")
+    assert_close(host(tp), d1, 1e-6, "disp")
+    # second iteration with an identical delta: the relative change is 0 < 1e-6 -> displacement zeroed
+    f2, c2, d2 = oracle.flow_update(f1, c1, delta[:, :2], delta[:, 2:3], d1, 8, 448, 448)
+    ops.flow_update_(tf, tc, dev(delta), tp, 8, 448, 448, zero_small=True, first_iteration=False)
+    assert np.all(d2 == 0)
+    assert_close(host(tp), d2, 1e-6, "disp 2")
+    assert_close(host(tf), f2, 1e-6, "flow 2")
+
+
+@pytest.mark.parametrize("tag,symmetric,attenuate", [("sym_up_att", True, True), ("plain", False, False),
+                                                       ("sym_noup_att", True, True), ("up_noatt", False, False)])
+def test_g6_golden_match_post(tag, symmetric, attenuate):
+    from gfnet_amd import ops
+
+    g = load_golden("g6_match_post")
+    warp, cert = ops.match_post(dev(g[f"{tag}.flow"]), dev(g[f"{tag}.cert"]),
+                                dev(g[f"{tag}.cert16"]) if attenuate else None, symmetric=symmetric)
+    assert_close(host(warp)[0], g[f"{tag}.warp"], 1e-6, "warp")
+    assert_close(host(cert)[0], g[f"{tag}.certainty"], 2e-6, "certainty")
+
+
+# ---- A9 homography solve ---------------------------------------------------------------------------
+def _ace(Ha, Hb, S=448):
+    return oracle.corner_error(Ha, Hb, S, S, clamp=1e9)
+
+
+def _points(seed, Bt, N, noise, outliers):
+    from test_homography_cpu import make_points, random_h
+
+    rng = np.random.default_rng(seed)
+    Hs = [random_h(rng) for _ in range(Bt)]
+    return Hs, np.stack([make_points(rng, H, N, noise=noise, outliers=outliers) for H in Hs])
+
+
+def test_convert_matches_bit_exact():
+    from gfnet_amd import ops
+
+    g = load_golden("g8_estimation")
+    w1, h1, w2, h2 = [int(v) for v in g["demo.sizes"]]
+    pts = host(ops.convert_matches(dev(g["demo.matches"]), w1, h1, w2, h2))
+    np.testing.assert_array_equal(pts, oracle.convert_matches(g["demo.matches"], w1, h1, w2, h2))
+    np.testing.assert_allclose(pts[:, :2], g["demo.pos_a"], rtol=1e-6)
+    np.testing.assert_allclose(pts[:, 2:], g["demo.pos_b"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("stage", [1, 2, 0])
+def test_ransac_matches_oracle_hypothesis_for_hypothesis(stage):
+    from gfnet_amd import ops
+
+    Hs, pts = _points(21, 4, 3000, noise=0.6, outliers=0.35)
+    H, ninl, best, mask = ops.find_homography(dev(pts), thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True)
+    Ho, no, bo, mo = oracle.homography_ransac(pts, thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True)
+    np.testing.assert_array_equal(host(best), bo)   # same RNG, same counts, same tie-breaking
+    np.testing.assert_array_equal(host(ninl), no)
+    np.testing.assert_array_equal(host(mask), mo)
+    Hg = host(H)
+    for b in range(4):
+        assert _ace(Ho[b], Hg[b]) < 1e-3, (stage, b, _ace(Ho[b], Hg[b]))  # north_star: within 1e-3 px of the reference path
+        if stage == 0:
+            assert _ace(Hs[b], Hg[b]) < 0.3
+
+
+def test_ransac_noise_free_and_failure_convention():
+    from gfnet_amd import ops
+
+    Hs, pts = _points(22, 2, 5000, noise=0.0, outliers=0.0)
+    H, ninl, best = ops.find_homography(dev(pts), iters=64, seed=1)
+    assert list(host(ninl)) == [5000, 5000] and list(host(best)) == [0, 0]
+    for b in range(2):
+        assert _ace(Hs[b].astype(np.float32), host(H)[b]) < 1e-3
+    # degenerate input -> diag(0,0,1), estimation.py:74-76
+    H, ninl, best = ops.find_homography(torch.ones(1, 50, 4, device="cuda"), iters=16)
+    np.testing.assert_array_equal(host(H)[0], np.diag([0.0, 0.0, 1.0]))
+    assert host(best)[0] == -1
+    H, ninl, best = ops.find_homography(torch.zeros(1, 3, 4, device="cuda"), iters=16)
+    np.testing.assert_array_equal(host(H)[0], np.diag([0.0, 0.0, 1.0]))
+
+
+def test_weighted_grid_dlt_matches_oracle():
+    from gfnet_amd import ops
+
+    Hs, pts = _points(23, 3, 4001, noise=0.4, outliers=0.0)  # odd count: exercises the MFMA tail
+    w = np.random.default_rng(3).uniform(0.05, 1.0, size=(3, 4001)).astype(np.float32)
+    H, ok = ops.homography_dlt(dev(pts), dev(w))
+    Ho, oko = oracle.homography_dlt(pts, w.astype(np.float64))
+    assert host(ok).all() and oko.all()
+    for b in range(3):
+        assert _ace(Ho[b], host(H)[b]) < 1e-3
+        assert _ace(Hs[b], host(H)[b]) < 0.2
+    H1, _ = ops.homography_dlt(dev(pts), None)
+    Ho1, _ = oracle.homography_dlt(pts)
+    assert _ace(Ho1[0], host(H1)[0]) < 1e-3
