@@ -107,7 +107,39 @@ __global__ __launch_bounds__(256) void kde_reduce_kernel(const float *__restrict
     out[idx] = s;
 }
 
+// GFNet.sample's elementwise steps (model/network.py:391-393, 409-410)
+__global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ c, float *__restrict__ out, long n, float thr) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = c[i] > thr ? 1.f : c[i];
+}
+
+__global__ __launch_bounds__(256) void balance_kernel(const float *__restrict__ density, float *__restrict__ p, long n,
+                                                      float min_density, float floor_p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float d = density[i];
+        p[i] = d < min_density ? floor_p : 1.f / (d + 1.f);
+    }
+}
+
 }  // namespace
+
+GFN_EXPORT int gfn_threshold_certainty(const float *certainty, float *out, int64_t n, float thresh, gfn_stream_t stream) {
+    if (!certainty || !out || n < 0) return gfn::fail(GFN_ERR_INVALID_ARG, "threshold_certainty: bad argument");
+    if (n == 0) return GFN_OK;
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, certainty, out,
+                       (long)n, thresh);
+    return gfn::check_launch("threshold_kernel");
+}
+
+GFN_EXPORT int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p,
+                                   gfn_stream_t stream) {
+    if (!density || !p || n < 0) return gfn::fail(GFN_ERR_INVALID_ARG, "balance_weights: bad argument");
+    if (n == 0) return GFN_OK;
+    hipLaunchKernelGGL(balance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, density, p,
+                       (long)n, min_density, floor_p);
+    return gfn::check_launch("balance_kernel");
+}
 
 GFN_EXPORT int gfn_kde_msplit(int Bt, int N, int M) {
     // enough blocks to fill 256 CUs x 8, but keep >= 512 reference points per split

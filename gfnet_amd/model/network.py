@@ -1,0 +1,260 @@
+"""Hot-path counterpart of the reference's model/network.py.
+
+What is kept: the names and call signatures a caller of the reference sees --
+`GFNet(conf, ...)` with `forward / match / sample / corr_volume / pos_embed`, and `ConvRefiner`
+with the reference's parameter layout (`block1`, `hidden_blocks`, `out_conv`, `disp_emb`), so a
+reference checkpoint's `conv_refiner.*` tensors load unchanged and `estimation.demo_estimation` /
+`test.py` can drive this class.
+
+What is different: every step between the feature pyramids and the sampled matches runs in the
+gfx950 kernels of csrc/ (through gfnet_amd.ops): global correlation + soft-argmax, the refiner's
+two gathers + displacement embedding + local correlation (written straight into the concat
+buffer), the flow update, the inter-scale resize, match() post-processing, the KDE of sample().
+The DINOv2 / cross-attention / FPN backbone is NOT part of this package (BASELINE north_star: "host
+code stays PyTorch-ROCm for the FPN/transformer backbone"): pass it in as `backbone=`, a callable
+`backbone(images, upsample) -> (pyramid_A, pyramid_B)` with the dict layout of
+GFNet.extract_features (model/network.py:156-201), or feed pyramids directly to
+`forward_pyramids` / `match_pyramids`.  The refiner's depthwise/pointwise conv stack
+(model/network.py:560-563) is ordinary torch.nn (MIOpen) -- SURVEY 8(f) N1.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.kde import kde
+
+SCALES = ("16", "8", "4", "2", "1")
+
+
+class ConvRefiner(nn.Module):
+    """Per-scale refiner (reference: model/network.py:444-564).
+
+    forward(num_grid, x, y, flow, scale_factor=1, logits=None) -> (delta_flow, delta_certainty,
+    local_corr).  Input assembly (network.py:533-558) is fused in HIP; the conv stack is torch.
+    """
+
+    def __init__(self, in_dim=6, hidden_dim=16, out_dim=2, dw=False, kernel_size=5, hidden_blocks=3,
+                 displacement_emb=None, displacement_emb_dim=None, local_corr_num=None, corr_in_other=None,
+                 no_im_B_fm=False, amp=False, concat_logits=False, use_bias_block_1=True, use_cosine_corr=False,
+                 disable_local_corr_grad=False, is_classifier=False, sample_mode="bilinear", norm_type=nn.BatchNorm2d,
+                 bn_momentum=0.1, amp_dtype=torch.float16):
+        super().__init__()
+        if sample_mode != "bilinear":
+            raise ValueError("only bilinear sampling is implemented (the reference's setting)")
+        self.bn_momentum = bn_momentum
+
+        def block(cin, cout, bias=True):
+            groups = cin if dw else 1
+            if dw and cout % cin:
+                raise ValueError("depthwise block needs out_dim divisible by in_dim")
+            norm = norm_type(cout, momentum=bn_momentum) if norm_type is nn.BatchNorm2d else norm_type(num_channels=cout)
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size, 1, kernel_size // 2, groups=groups, bias=bias), norm,
+                                 nn.ReLU(inplace=True), nn.Conv2d(cout, cout, 1, 1, 0))
+
+        self.block1 = block(in_dim, hidden_dim, bias=use_bias_block_1)
+        self.hidden_blocks = nn.Sequential(*[block(hidden_dim, hidden_dim) for _ in range(hidden_blocks)])
+        self.out_conv = nn.Conv2d(hidden_dim, out_dim, 1, 1, 0)
+        self.has_displacement_emb = bool(displacement_emb)
+        if self.has_displacement_emb:
+            self.disp_emb = nn.Conv2d(2, displacement_emb_dim, 1, 1, 0)
+        self.local_corr_radius = local_corr_num
+        self.local_corr_num = local_corr_num
+        self.corr_in_other = corr_in_other
+        self.amp = amp
+        self.amp_dtype = amp_dtype
+        self.sample_mode = sample_mode
+
+    def assemble(self, num_grid, x, y, flow, scale_factor=1):
+        """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view."""
+        if not self.has_displacement_emb:
+            raise NotImplementedError("refiners without displacement embedding are not used by GFNet")
+        c = x.shape[1]
+        dd = self.disp_emb.weight.shape[0]
+        use_corr = bool(self.corr_in_other)
+        d = ops.refiner_input(num_grid, x, y, flow, self.disp_emb.weight, self.disp_emb.bias,
+                              self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr)
+        return d, (d[:, 2 * c + dd:] if use_corr else None)
+
+    def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None):
+        d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor)
+        with torch.autocast("cuda", enabled=bool(self.amp), dtype=self.amp_dtype):
+            h = self.hidden_blocks(self.block1(d))
+        out = self.out_conv(h.float())
+        return out[:, :2], out[:, 2:3], local_corr
+
+
+def _refiner_for(feat_dim, disp_dim, radius):
+    """The constructor arguments GFNet uses for each scale (model/network.py:79-154)."""
+    has_corr = radius > 0
+    dim = 2 * feat_dim + disp_dim + ((2 * radius + 1) ** 2 if has_corr else 0)
+    return ConvRefiner(dim, dim, 2 + 1, kernel_size=5, dw=True, hidden_blocks=8, displacement_emb="linear",
+                       displacement_emb_dim=disp_dim, local_corr_num=radius, corr_in_other=has_corr, amp=True,
+                       disable_local_corr_grad=True, bn_momentum=0.01)
+
+
+class GFNet(nn.Module):
+    """Grid-based dense matcher, hot path on MI355X (reference: model/network.py:17-440)."""
+
+    def __init__(self, conf, sample_mode="threshold_balanced", exact_softmax=False, amp=True, amp_dtype=torch.float16,
+                 initial_res=(448, 448), upsample_res=(560, 560), symmetric=False, upsample_preds=False,
+                 attenuate_cert=False, backbone=None, conv_refiner=None):
+        super().__init__()
+        m = conf["matcher"]
+        self.num_grid = list(m["num_grid"])
+        self.radius = list(m["radius"])
+        self.num_itr = list(m["num_itr"])
+        self.backbone = backbone
+        if conv_refiner is None:
+            chs = conf["encoder_cfg"]["feat_chs"]  # coarse to fine: [64, 32, 16, 8]
+            feat = [chs[0], chs[0], chs[1], chs[2], chs[3]]
+            conv_refiner = nn.ModuleDict({s: _refiner_for(feat[i], m["displacement_dim"][i], self.radius[i])
+                                          for i, s in enumerate(SCALES)})
+        self.conv_refiner = conv_refiner
+        self.sample_mode = sample_mode
+        self.sample_thresh = 0.05
+        self.upsample_preds = upsample_preds
+        self.upsample_res = upsample_res
+        self.symmetric = symmetric
+        self.attenuate_cert = attenuate_cert
+        self.h_resized, self.w_resized = initial_res
+        self.exact_softmax = exact_softmax
+        self.amp, self.amp_dtype = amp, amp_dtype
+        self.ransac_iters = 2000  # OpenCV's default maxIters for findHomography
+
+    # ---- the two methods GFNet.forward calls at scale 16 (network.py:251-252) -------------------
+    def corr_volume(self, feat0, feat1):
+        return ops.corr_volume(feat0, feat1)
+
+    def pos_embed(self, corr_volume):
+        return ops.pos_embed(corr_volume)
+
+    # ---- backbone hook ---------------------------------------------------------------------------
+    def extract_features(self, x, upsample=False):
+        if self.backbone is None:
+            raise NotImplementedError(
+                "no backbone attached: the DINOv2/FPN feature extractor stays ordinary PyTorch-ROCm host code and is not "
+                "part of gfnet_amd; pass backbone=... or call forward_pyramids()/match_pyramids() with feature pyramids")
+        return self.backbone(x, upsample)
+
+    def upsample_grids(self, hs):
+        """num_grid_up of match() (network.py:329) and the matching radii / iteration counts."""
+        g = int(hs / 14)
+        grids = [g, 2 * g, 4 * g, 8 * g]
+        return grids, self.radius[-len(grids):], self.num_itr[-len(grids):]
+
+    # ---- coarse-to-fine loop (network.py:230-281) ---------------------------------------------------
+    def forward_pyramids(self, features0, features1, image_hw, symmetric=False, upsample=False, scale_factor=1,
+                         pre_corresps=None):
+        """GFNet.forward after feature extraction.  features*: dict scale -> (B,c,h,w), coarse to
+        fine, keys "16".."1" (or "8".."1" when upsample).  image_hw: (H0, W0) of the network input."""
+        H0, W0 = image_hw
+        if symmetric:  # network.py:213-222
+            features0, features1 = ({s: torch.cat((features0[s], features1[s])) for s in features0},
+                                    {s: torch.cat((features1[s], features0[s])) for s in features0})
+        if upsample:
+            num_grid, _, num_itr = self.num_grid_up, self.radius_up, self.num_itr_up
+        else:
+            num_grid, num_itr = self.num_grid, self.num_itr
+        scales = list(features0.keys())
+        corresps = {}
+        flow = certainty = None
+        for idx, scale in enumerate(scales):
+            f0, f1 = features0[scale], features1[scale]
+            if idx == 0:
+                if upsample:
+                    if pre_corresps is None:
+                        raise ValueError("upsampling refinement needs pre_corresps")
+                    flow = ops.interpolate_bilinear(pre_corresps["flow"], num_grid[0])          # :238-243
+                    certainty = ops.interpolate_bilinear(pre_corresps["certainty"], num_grid[0])  # :244-249
+                else:
+                    flow = ops.corr_softargmax(f0, f1)                                           # :251-252
+                    certainty = torch.zeros((flow.shape[0], 1) + tuple(flow.shape[2:]), device=flow.device)  # :253
+            corresps[scale] = {}
+            disp_prev = torch.empty_like(flow)
+            for itr in range(num_itr[idx]):
+                d_flow, d_cert, _ = self.conv_refiner[scale](num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
+                delta = torch.cat((d_flow.float(), d_cert.float()), dim=1)
+                flow, certainty = flow.clone(), certainty.clone()  # each iteration's result is kept (corresps)
+                ops.flow_update_(flow, certainty, delta, disp_prev, int(scale), W0, H0, zero_small=not self.training,
+                                 first_iteration=(itr == 0))                                     # :262-268
+                corresps[scale][itr + 1] = {"flow": flow, "certainty": certainty}
+            if scale != "1":                                                                      # :271-281
+                flow = ops.interpolate_bilinear(flow, num_grid[idx + 1])
+                certainty = ops.interpolate_bilinear(certainty, num_grid[idx + 1])
+        return corresps
+
+    def forward(self, batch, symmetric=False, upsample=False, scale_factor=1, pre_corresps=None, visualization=False):
+        im0, im1 = batch["im_A"], batch["im_B"]
+        H0, W0 = im0.shape[-2:]
+        f0, f1 = self.extract_features(torch.cat([im0, im1], dim=0), upsample)
+        return self.forward_pyramids(f0, f1, (H0, W0), symmetric=symmetric, upsample=upsample, scale_factor=scale_factor,
+                                     pre_corresps=pre_corresps)
+
+    # ---- match (network.py:285-384) ------------------------------------------------------------------
+    def _finish_match(self, corresps, corresps_up, batched):
+        num_itr = self.num_itr_up if corresps_up is not None else self.num_itr
+        last = (corresps_up if corresps_up is not None else corresps)["1"][num_itr[-1]]
+        c16 = corresps["16"][self.num_itr[0]]["certainty"] if self.attenuate_cert else None
+        warp, certainty = ops.match_post(last["flow"], last["certainty"], c16, symmetric=self.symmetric)
+        return (warp, certainty) if batched else (warp[0], certainty[0])
+
+    @torch.inference_mode()
+    def match_pyramids(self, pyr0, pyr1, pyr0_up=None, pyr1_up=None, batched=True):
+        """match() on precomputed feature pyramids: the 448 pass, the optional 560 refinement pass
+        seeded by it (upsample_preds), certainty attenuation, post-processing."""
+        self.train(False)
+        corresps = self.forward_pyramids(pyr0, pyr1, (self.h_resized, self.w_resized), symmetric=self.symmetric)
+        corresps_up = None
+        if self.upsample_preds:
+            hs, ws = self.upsample_res
+            self.num_grid_up, self.radius_up, self.num_itr_up = self.upsample_grids(hs)
+            if pyr0_up is None:
+                raise ValueError("upsample_preds=True needs the feature pyramids of the upsample resolution")
+            sf = math.sqrt(hs * ws / (self.w_resized * self.h_resized))
+            corresps_up = self.forward_pyramids(pyr0_up, pyr1_up, (hs, ws), symmetric=self.symmetric, upsample=True,
+                                                scale_factor=sf, pre_corresps=corresps["1"][self.num_itr[-1]])
+        return self._finish_match(corresps, corresps_up, batched)
+
+    @torch.inference_mode()
+    def match(self, im0, im1, *args, batched=True):
+        """Same contract as the reference: paths / PIL images / tensors in, (warp, certainty) out.
+        Needs a backbone; image resize + ImageNet normalisation are done with torch."""
+        from ..utils.image import load_pair
+
+        im_a, im_b, batched = load_pair(im0, im1, batched)
+        dev = torch.device("cuda")
+
+        def pyramids(res, upsample):
+            a, b = (t.to(dev) for t in _resize_normalise(im_a, im_b, res))
+            return self.extract_features(torch.cat([a, b]), upsample)
+
+        p0, p1 = pyramids((self.h_resized, self.w_resized), False)
+        u0 = u1 = None
+        if self.upsample_preds:
+            u0, u1 = pyramids(self.upsample_res, True)
+        return self.match_pyramids(p0, p1, u0, u1, batched=batched)
+
+    # ---- sample (network.py:385-414) --------------------------------------------------------------------
+    def sample(self, matches, certainty, num=5_000):
+        matches = matches.reshape(-1, 4)
+        certainty = certainty.reshape(-1)
+        if "threshold" in self.sample_mode:
+            certainty = ops.threshold_certainty(certainty, self.sample_thresh)
+        expansion = 4 if "balanced" in self.sample_mode else 1
+        good = torch.multinomial(certainty, num_samples=min(expansion * num, len(certainty)), replacement=False)
+        good_matches, good_certainty = matches[good], certainty[good]
+        if "balanced" not in self.sample_mode:
+            return good_matches, good_certainty
+        # the reference uses half precision and the full set on a GPU (network.py:406-407)
+        density = kde(good_matches, std=0.1, half=True, down=1)
+        p = ops.balance_weights(density.float())
+        balanced = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False)
+        return good_matches[balanced], good_certainty[balanced]
+
+
+def _resize_normalise(im_a, im_b, res):
+    from ..utils.image import resize_normalise
+
+    return resize_normalise(im_a, res), resize_normalise(im_b, res)

@@ -159,6 +159,25 @@ def kde_density(x, y=None, std=0.1, y_row_stride=None):
     return out[0] if squeeze else out
 
 
+def threshold_certainty(certainty, thresh):
+    """certainty[certainty > thresh] = 1 on a copy (model/network.py:391-393)."""
+    dev = require_gpu(certainty)
+    c = f32c(certainty)
+    out = torch.empty_like(c)
+    check(_L().gfn_threshold_certainty(ptr(c), ptr(out), c.numel(), float(thresh), stream_ptr(dev)), "gfn_threshold_certainty")
+    return out
+
+
+def balance_weights(density, min_density=10.0, floor_p=1e-7):
+    """p = 1/(density+1); p[density < 10] = 1e-7 (model/network.py:409-410)."""
+    dev = require_gpu(density)
+    d = f32c(density)
+    p = torch.empty_like(d)
+    check(_L().gfn_balance_weights(ptr(d), ptr(p), d.numel(), float(min_density), float(floor_p), stream_ptr(dev)),
+          "gfn_balance_weights")
+    return p
+
+
 def convert_matches(matches, wA, hA, wB, hB):
     """estimation.py:26-45 on the device: (...,4) normalised warp rows -> pixel (x,y,u,v), float32."""
     dev = require_gpu(matches)

@@ -145,6 +145,13 @@ int64_t gfn_kde_scratch_floats(int Bt, int N, int M, int D);
 int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, int M, int D, int64_t y_row_stride,
                     int64_t y_batch_stride, double std, float *scratch, int64_t scratch_floats, gfn_stream_t stream);
 
+/* GFNet.sample's elementwise steps (model/network.py:385-414):
+ *   gfn_threshold_certainty: out = certainty > thresh ? 1 : certainty            (:391-393)
+ *   gfn_balance_weights:     p = density < min_density ? floor_p : 1/(density+1)  (:409-410; 10, 1e-7)
+ * (the two torch.multinomial draws stay with torch's generator, as in the reference). */
+int gfn_threshold_certainty(const float *certainty, float *out, int64_t n, float thresh, gfn_stream_t stream);
+int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p, gfn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Homography solve -- estimation.py:60-77 (cv2.findHomography(..., cv2.RANSAC, confidence=0.99999,
  * ransacReprojThreshold=3) in the reference; OpenCV's published pipeline restated, see

@@ -1,0 +1,109 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gfnet_hip.h declares
+(no compute calls without a GPU), host logic of the estimation mirror against the goldens, the
+network mirror's parameter layout against the reference's state_dict keys, the no-CPU-fallback rule."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from gfnet_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "gfnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gfn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/gfnet_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert L.gfn_abi_version() == 1
+
+
+def test_argument_errors_return_codes_without_a_gpu():
+    from gfnet_amd import _lib
+
+    L = _lib.lib()
+    # null pointers / bad sizes are rejected before anything touches the device
+    assert L.gfn_local_corr_fwd(None, 0, None, None, None, 0, 1, 16, 4, 8, 8, 2, 0, 8, 8, None) == -1
+    assert b"null" in L.gfn_last_error()
+    assert L.gfn_interp_bilinear_fwd(None, None, 1, 2, 2, 2, 2, None) == -1
+    assert L.gfn_kde_msplit(1, 20000, 20000) >= 1
+    assert L.gfn_homography_scratch_bytes(2, 100) >= 2 * 100 * 76
+
+
+def test_product_ops_refuse_cpu_tensors():
+    from gfnet_amd import ops
+    from gfnet_amd._lib import GfnError
+    from gfnet_amd.utils.kde import kde
+
+    with pytest.raises(GfnError):
+        ops.corr_softargmax(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4))
+    with pytest.raises(GfnError):
+        kde(torch.zeros(16, 4), half=False)
+    with pytest.raises(GfnError):
+        ops.find_homography(torch.zeros(1, 10, 4))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gfnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_estimation_mirror_against_goldens():
+    from gfnet_amd import estimation as E
+
+    g = load_golden("g8_estimation")
+    np.testing.assert_allclose(E.auc(list(g["errors"]), [3, 5, 10, 20]), g["aucs"], rtol=1e-12)
+    np.testing.assert_allclose(E.auc(list(g["errors_few"]), [3, 5, 10, 20]), g["aucs_few"], rtol=1e-12)
+    wq, hq, ws, hs = [int(v) for v in g["conv_sizes"]]
+    pa, pb = E.convert_coordinates(g["conv_a"], g["conv_b"], wq, hq, ws, hs)
+    np.testing.assert_array_equal(pa, g["conv_pa"])
+    np.testing.assert_array_equal(pb, g["conv_pb"])
+    ta, tb = E.convert_coordinates(torch.from_numpy(g["conv_a"]), torch.from_numpy(g["conv_b"]), wq, hq, ws, hs)
+    np.testing.assert_allclose(ta.numpy(), g["conv_pa"], rtol=1e-6)
+    w1, h1, _, _ = [int(v) for v in g["demo.sizes"]]
+    for tag in ("near", "far"):
+        assert abs(E.corner_error(g["demo.H_gt"], g[f"demo.{tag}.H_pred"], w1, h1) - float(g[f"demo.{tag}.ace"])) < 1e-9
+    # failed solve: diag(0,0,1) -> the reference's value for that case
+    ace_none = E.corner_error(g["demo.H_gt"], np.diag([0.0, 0.0, 1.0]), w1, h1)
+    ref = float(g["demo.none.ace"])
+    assert (np.isnan(ref) and np.isnan(ace_none)) or abs(ace_none - ref) < 1e-9
+
+
+def test_refiner_parameter_layout_matches_reference_state_dict():
+    from gfnet_amd.model.network import ConvRefiner
+
+    g = load_golden("g4_refiner_prefix")
+    c, disp, r = 8, 6, 2
+    dim = 2 * c + disp + (2 * r + 1) ** 2
+    ref = ConvRefiner(dim, dim, 3, kernel_size=5, dw=True, hidden_blocks=2, displacement_emb="linear",
+                      displacement_emb_dim=disp, local_corr_num=r, corr_in_other=True, amp=True, bn_momentum=0.01)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    missing, unexpected = ref.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def test_gfnet_builds_from_basic_config_shapes():
+    from gfnet_amd.model.network import GFNet
+
+    conf = {"encoder_cfg": {"feat_chs": [64, 32, 16, 8]},
+            "matcher": {"num_grid": [32, 32, 64, 128, 256], "radius": [7, 6, 4, 2, 0],
+                        "displacement_dim": [64, 64, 32, 16, 8], "num_itr": [1, 1, 1, 1, 1]}}  # gfnet_configs/basic.json:19-27
+    m = GFNet(conf, symmetric=True, upsample_preds=True, attenuate_cert=True)
+    # input widths of the five refiners (network.py:79-154): 2c + disp + (2r+1)^2
+    assert [m.conv_refiner[s].block1[0].in_channels for s in ("16", "8", "4", "2", "1")] == [417, 361, 177, 73, 24]
+    assert m.upsample_grids(560) == ([40, 80, 160, 320], [6, 4, 2, 0], [1, 1, 1, 1])
+    with pytest.raises(NotImplementedError):
+        m.extract_features(torch.zeros(2, 3, 448, 448))

@@ -1,0 +1,187 @@
+"""GPU: the network mirror (gfnet_amd.model.network) against reference-generated goldens G4/G5/G7
+and an end-to-end known-homography run of the whole post-backbone path."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def _toy_refiner(c, disp, r, hidden_blocks, sd):
+    from gfnet_amd.model.network import ConvRefiner
+
+    K = (2 * r + 1) ** 2 if r > 0 else 0
+    dim = 2 * c + disp + K
+    ref = ConvRefiner(dim, dim, 3, kernel_size=5, dw=True, hidden_blocks=hidden_blocks, displacement_emb="linear",
+                      displacement_emb_dim=disp, local_corr_num=r, corr_in_other=r > 0, amp=False, bn_momentum=0.01)
+    ref.load_state_dict(sd, strict=True)
+    return ref.cuda().eval()
+
+
+def test_g4_refiner_forward_matches_reference():
+    g = load_golden("g4_refiner_prefix")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    ref = _toy_refiner(8, 6, int(g["r"]), int(g["hidden_blocks"]), sd)
+    with torch.no_grad():
+        dflow, dcert, lc = ref(int(g["G"]), dev(g["x"]), dev(g["y"]), dev(g["flow"]), scale_factor=float(g["scale_factor"]))
+    assert_close(host(lc), g["local_corr"], 1e-4, "local_corr")
+    assert_close(host(dflow), g["delta_flow"], 1e-4, "delta_flow")  # fp32 convs (amp off): MIOpen vs ATen-CPU
+    assert_close(host(dcert), g["delta_cert"], 1e-4, "delta_cert")
+    sd1 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd1.")}
+    ref1 = _toy_refiner(8, 6, 0, int(g["hidden_blocks"]), sd1)
+    with torch.no_grad():
+        dflow1, dcert1, lc1 = ref1(int(g["G"]), dev(g["x"]), dev(g["y"]), dev(g["flow"]), scale_factor=1.0)
+    assert lc1 is None
+    assert_close(host(dflow1), g["delta_flow_nocorr"], 1e-4, "delta_flow (no corr)")
+
+
+def _g5_model(g):
+    from gfnet_amd.model.network import GFNet
+    import torch.nn as nn
+
+    feat_ch, disp, radius = list(g["feat_ch"]), list(g["disp"]), list(g["radius"])
+    refiners = {}
+    for i, s in enumerate(("16", "8", "4", "2", "1")):
+        sd = {k[len(f"sd.{s}."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"sd.{s}.")}
+        refiners[s] = _toy_refiner(int(feat_ch[i]), int(disp[i]), int(radius[i]), 1, sd)
+    conf = {"matcher": {"num_grid": [int(v) for v in g["num_grid"]], "radius": [int(v) for v in radius],
+                        "num_itr": [int(v) for v in g["num_itr"]], "displacement_dim": [int(v) for v in disp]}}
+    m = GFNet(conf, symmetric=True, conv_refiner=nn.ModuleDict(refiners)).cuda().eval()
+    return m
+
+
+def test_g5_forward_loop_both_passes_match_reference():
+    g = load_golden("g5_forward_loop")
+    m = _g5_model(g)
+    scales = ("16", "8", "4", "2", "1")
+    p0 = {s: dev(g[f"pyr0.{s}"]) for s in scales}
+    p1 = {s: dev(g[f"pyr1.{s}"]) for s in scales}
+    with torch.no_grad():
+        cor = m.forward_pyramids(p0, p1, (56, 56), symmetric=True)
+    for s in scales:
+        for itr in cor[s]:
+            # flows live in [-1,1]; the toy refiners amplify fp32 conv noise a little across 5 scales
+            assert_close(host(cor[s][itr]["flow"]), g[f"flow.{s}.{itr}"], 2e-4, f"flow {s}.{itr}")
+            assert_close(host(cor[s][itr]["certainty"]), g[f"cert.{s}.{itr}"], 2e-4, f"cert {s}.{itr}")
+    # upsample pass seeded by the finest correspondences (network.py:235-249), scale_factor 1.25
+    up_scales = ("8", "4", "2", "1")
+    u0 = {s: dev(g[f"up0.{s}"]) for s in up_scales}
+    u1 = {s: dev(g[f"up1.{s}"]) for s in up_scales}
+    m.num_grid_up = [int(v) for v in g["num_grid_up"]]
+    m.num_itr_up = [int(v) for v in g["num_itr_up"]]
+    m.radius_up = m.radius[-4:]
+    pre = {"flow": dev(g["flow.1.1"]), "certainty": dev(g["cert.1.1"])}
+    with torch.no_grad():
+        cu = m.forward_pyramids(u0, u1, (72, 72), symmetric=True, upsample=True, scale_factor=1.25, pre_corresps=pre)
+    for s in up_scales:
+        for itr in cu[s]:
+            assert_close(host(cu[s][itr]["flow"]), g[f"upflow.{s}.{itr}"], 2e-4, f"upflow {s}.{itr}")
+            assert_close(host(cu[s][itr]["certainty"]), g[f"upcert.{s}.{itr}"], 2e-4, f"upcert {s}.{itr}")
+
+
+def test_g7_sample_density_and_weights_on_reference_candidates():
+    """torch.multinomial on the GPU draws a different stream than the reference's CPU generator, so
+    the draws cannot be compared; what the kernels compute for a given candidate set can."""
+    from gfnet_amd import ops
+    from gfnet_amd.model.network import GFNet
+
+    g = load_golden("g7_sample")
+    warp, cert = g["warp"], g["certainty"]
+    th = host(ops.threshold_certainty(dev(cert), 0.05))
+    exp = cert.copy()
+    exp[exp > 0.05] = 1
+    np.testing.assert_array_equal(th, exp)
+    cand = g["threshold_balanced.matches"]  # 500 rows the reference itself sampled
+    dens = oracle.kde(cand, 0.1, half=False)
+    p = host(ops.balance_weights(dev(dens)))
+    pe = 1 / (dens + 1)
+    pe[dens < 10] = 1e-7
+    np.testing.assert_allclose(p, pe, rtol=1e-6)
+    # end to end on the device: shapes, membership, determinism under a seed
+    me = types.SimpleNamespace(sample_mode="threshold_balanced", sample_thresh=0.05)
+    torch.manual_seed(0)
+    m1, c1 = GFNet.sample(me, dev(warp), dev(cert), num=500)
+    torch.manual_seed(0)
+    m2, c2 = GFNet.sample(me, dev(warp), dev(cert), num=500)
+    assert m1.shape == (500, 4) and c1.shape == (500,)
+    assert torch.equal(m1, m2)
+    rows = {tuple(r) for r in warp.reshape(-1, 4).round(6).tolist()}
+    assert all(tuple(r) in rows for r in host(m1).round(6).tolist())
+    assert float(c1.min()) > 0  # zero-certainty cells are never drawn
+    # balanced sampling flattens the density: sampled set is less concentrated than its candidate pool
+    me2 = types.SimpleNamespace(sample_mode="threshold", sample_thresh=0.05)
+    m3, _ = GFNet.sample(me2, dev(warp), dev(cert), num=500)
+    assert m3.shape == (500, 4)
+
+
+class _ExactRefiner(torch.nn.Module):
+    """Stands in for the learned conv stack: returns the displacement that moves the flow onto the
+    ground-truth warp (through the real displacement scaling of network.py:262-263)."""
+
+    def __init__(self, gt_fn, scale, size):
+        super().__init__()
+        self.gt_fn, self.scale, self.size = gt_fn, scale, size
+
+    def forward(self, num_grid, x, y, flow, scale_factor=1):
+        gt = self.gt_fn(num_grid, flow.shape[0])
+        delta = (gt - flow) * (4 * self.size) / self.scale
+        cert = torch.full((flow.shape[0], 1, num_grid, num_grid), 3.0, device=flow.device)
+        return delta, cert, None
+
+
+def test_end_to_end_known_homography_through_the_whole_path():
+    """pyramids -> coarse-to-fine loop -> match post-processing -> sample -> device RANSAC/DLT -> ACE."""
+    from gfnet_amd import estimation as E
+    from gfnet_amd.model.network import GFNet
+    from test_homography_cpu import random_h
+    import torch.nn as nn
+
+    S = 448
+    rng = np.random.default_rng(5)
+    H = random_h(rng, S, amp=0.1)
+    Hinv = np.linalg.inv(H)
+
+    def warp_norm(Hm, G):
+        lin = (np.arange(G) * 2 + 1) / G - 1
+        gx, gy = np.meshgrid(lin, lin, indexing="xy")
+        px, py = (S - 1) * (gx + 1) / 2, (S - 1) * (gy + 1) / 2
+        w = Hm[2, 0] * px + Hm[2, 1] * py + Hm[2, 2]
+        u = (Hm[0, 0] * px + Hm[0, 1] * py + Hm[0, 2]) / w
+        v = (Hm[1, 0] * px + Hm[1, 1] * py + Hm[1, 2]) / w
+        return np.stack((2 * u / (S - 1) - 1, 2 * v / (S - 1) - 1)).astype(np.float32)
+
+    def gt_fn(G, nb):  # symmetric batch: A->B then B->A
+        return torch.from_numpy(np.stack([warp_norm(H, G), warp_norm(Hinv, G)])).cuda()
+
+    conf = {"matcher": {"num_grid": [32, 32, 64, 128, 256], "radius": [7, 6, 4, 2, 0], "num_itr": [1] * 5,
+                        "displacement_dim": [64, 64, 32, 16, 8]}}
+    refiners = nn.ModuleDict({s: _ExactRefiner(gt_fn, int(s), S) for s in ("16", "8", "4", "2", "1")})
+    m = GFNet(conf, symmetric=True, upsample_preds=False, attenuate_cert=True, conv_refiner=refiners).cuda().eval()
+    sides = {"16": 32, "8": 56, "4": 112, "2": 224, "1": 448}
+    chs = {"16": 64, "8": 64, "4": 32, "2": 16, "1": 8}
+    g = torch.Generator(device="cuda").manual_seed(0)
+    p0 = {s: torch.randn(1, chs[s], sides[s], sides[s], device="cuda", generator=g) for s in sides}
+    p1 = {s: torch.randn(1, chs[s], sides[s], sides[s], device="cuda", generator=g) for s in sides}
+    warp, cert = m.match_pyramids(p0, p1, batched=False)
+    assert warp.shape == (256, 512, 4) and cert.shape == (256, 512)
+    torch.manual_seed(1)
+    good, _ = m.sample(warp, cert, 5000)
+    assert good.shape == (5000, 4)
+    Hp = host(E.estimate_homographies(good, (S, S, S, S), iters=256))[0]
+    ace = E.corner_error(H, Hp, S, S)
+    assert ace < 0.05, ace  # exact flow: only fp32 grid/flow rounding remains
