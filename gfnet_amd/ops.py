@@ -16,6 +16,22 @@ def _L():
     return _lib.lib()
 
 
+# bench.py sets this to a dict {name: [(start_event, end_event), ...]} to time individual launches
+# with HIP events on the launch stream; None (the default) costs nothing.
+kernel_events = None
+
+
+def _timed(name, launch):
+    if kernel_events is None or name not in kernel_events:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = launch()
+    e1.record()
+    kernel_events[name].append((e0, e1))
+    return r
+
+
 def corr_softargmax(feat0, feat1):
     """pos_embed(corr_volume(feat0, feat1)) without writing the volume (model/network.py:251-252, 415-440).
     feat0 (B,C,H0,W0), feat1 (B,C,H1,W1) -> flow (B,2,H0,W0)."""
@@ -62,6 +78,8 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     x, y, fl = f32c(x), f32c(y), f32c(flow)
     B, C, Hs, Ws = x.shape
     G = int(num_grid)
+    if tuple(y.shape) != (B, C, Hs, Ws) or tuple(fl.shape) != (B, 2, G, G):
+        raise ValueError(f"refiner_input: y must be {(B, C, Hs, Ws)} and flow {(B, 2, G, G)}, got {tuple(y.shape)}, {tuple(fl.shape)}")
     w = f32c(disp_w).reshape(-1, 2)
     bvec = f32c(disp_b).reshape(-1)
     Dd = w.shape[0]
@@ -74,8 +92,9 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
                                      float(40 / 32 * scale_factor), st), "gfn_refiner_input_fwd")
     if corr_in_other:
         out = d[:, 2 * C + Dd:]
-        check(_L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(fl), c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs,
-                                      Ws, r, 0, Hs, Ws, st), "gfn_local_corr_fwd")
+        check(_timed(f"local_corr_c{C}_h{Hs}_g{G}_r{r}",
+                     lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(fl), c_vp(out.data_ptr()), CH * G * G,
+                                                     B, C, G, Hs, Ws, r, 0, Hs, Ws, st)), "gfn_local_corr_fwd")
     return d
 
 
@@ -107,6 +126,9 @@ def flow_update_(flow, certainty, delta, disp_prev, scale, W0, H0, zero_small=Tr
     displacement, 2 = certainty increment); disp_prev (B,2,G,G) carries the previous displacement."""
     dev = require_gpu(flow, certainty, delta, disp_prev)
     B, _, G, _ = flow.shape
+    if tuple(certainty.shape) != (B, 1, G, G) or tuple(disp_prev.shape) != (B, 2, G, G) or \
+            tuple(delta.shape[:1] + delta.shape[2:]) != (B, G, G) or delta.shape[1] < 3:
+        raise ValueError("flow_update_: inconsistent shapes")
     for t in (flow, certainty, disp_prev):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError("flow_update_: flow/certainty/disp_prev must be contiguous fp32 (updated in place)")
@@ -122,6 +144,8 @@ def match_post(flow, certainty, cert16=None, symmetric=True):
     dev = require_gpu(flow, certainty, cert16)
     fl, ce = f32c(flow), f32c(certainty)
     nb, _, G, _ = fl.shape
+    if tuple(ce.shape) != (nb, 1, G, G) or (cert16 is not None and cert16.shape[0] != nb) or (symmetric and nb % 2):
+        raise ValueError("match_post: inconsistent shapes")
     B = nb // 2 if symmetric else nb
     Gw = 2 * G if symmetric else G
     c16 = f32c(cert16) if cert16 is not None else None

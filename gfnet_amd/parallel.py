@@ -1,0 +1,50 @@
+"""Multi-GPU layout of the path: image pairs shard embarrassingly, one process per GPU
+(torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" for the CPU tests).  The reference has
+no inference-time parallelism at all (scripts/test_script.sh pins one GPU, test.py:61 loops pairs
+one by one); there is no exchange step anywhere on the path, so the only collective is the gather of
+the estimated 3x3 matrices (72 bytes per pair) at the end of a batch.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); no-op for one process.
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of items for `rank`: sizes differ by at most one, earlier ranks get the extra."""
+    q, r = divmod(n_items, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def gather_homographies(H_local, counts=None):
+    """All ranks end up with every pair's H, in pair order.  H_local: (n_local,3,3).  With unequal
+    shard sizes pass counts (list of per-rank sizes); blocks are padded to the largest for the
+    collective and trimmed afterwards."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return H_local
+    world = dist.get_world_size()
+    if counts is None:
+        counts = [H_local.shape[0]] * world
+    nmax = max(counts)
+    buf = H_local.new_zeros((nmax, 3, 3))
+    buf[: H_local.shape[0]] = H_local
+    out = H_local.new_empty((world * nmax, 3, 3))
+    dist.all_gather_into_tensor(out, buf.contiguous())
+    out = out.view(world, nmax, 3, 3)
+    return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)

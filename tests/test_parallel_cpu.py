@@ -1,0 +1,75 @@
+"""World-size-2 gloo test of the only collective on the path: sharding pairs and gathering H."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from gfnet_amd import parallel
+
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    lo, hi = parallel.shard_range(n_pairs, r, w)
+    # every pair's "H" is a function of its global index, so the gathered order can be checked
+    H_local = torch.stack([torch.full((3, 3), float(i), dtype=torch.float64) + torch.eye(3, dtype=torch.float64)
+                           for i in range(lo, hi)]) if hi > lo else torch.zeros((0, 3, 3), dtype=torch.float64)
+    counts = [parallel.shard_range(n_pairs, k, w)[1] - parallel.shard_range(n_pairs, k, w)[0] for k in range(w)]
+    H_all = parallel.gather_homographies(H_local, counts)
+    q.put((rank, lo, hi, H_all.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_pairs, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_shard_range_partitions_exactly():
+    from gfnet_amd.parallel import shard_range
+
+    for n in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_homographies_world2_even_and_ragged():
+    for n_pairs in (8, 7):
+        res = _run(n_pairs)
+        expect = np.stack([np.full((3, 3), float(i)) + np.eye(3) for i in range(n_pairs)])
+        for rank, lo, hi, H_all in res:
+            np.testing.assert_array_equal(H_all, expect)
+        assert res[0][1] == 0 and res[-1][2] == n_pairs
+
+
+def test_single_process_is_a_no_op():
+    from gfnet_amd import parallel
+
+    H = torch.eye(3, dtype=torch.float64)[None]
+    assert parallel.gather_homographies(H) is H
