@@ -17,8 +17,8 @@ c_int, c_i64, c_vp, c_float, c_double = ctypes.c_int, ctypes.c_int64, ctypes.c_v
 
 # name -> argtypes; every entry point returns int (GFN_OK or a negative error code)
 _SIGNATURES = {
-    "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp],
-    "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp],
+    "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp, c_i64, c_vp],
+    "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp, c_i64, c_vp],
     "gfn_avg_pool2": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "gfn_corr_softargmax_fwd": [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
     "gfn_corr_volume_fwd": [c_vp, c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
@@ -39,6 +39,7 @@ _SIGNATURES = {
 }
 # entry points that return a size instead of a status
 _SIZE_FUNCS = {
+    "gfn_local_corr_scratch_bytes": [c_int, c_int],
     "gfn_kde_scratch_floats": [c_int, c_int, c_int, c_int],
     "gfn_homography_scratch_bytes": [c_int, c_int],
 }
@@ -100,6 +101,19 @@ def require_gpu(*tensors):
         elif t.device != dev:
             raise GfnError(f"tensors on different devices: {dev} vs {t.device}")
     return dev
+
+
+_scratch = {}
+
+
+def scratch(device, nbytes):
+    """A per-device, grow-only int32 scratch buffer (stream-ordered reuse: one host thread per stream)."""
+    key = (device.type, device.index)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
+        _scratch[key] = buf
+    return buf
 
 
 def f32c(t):

@@ -16,7 +16,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # no implicit FMA contraction: coordinate arithmetic must round exactly like the reference's
          # fp32 ops (FMAs in the kernels are explicit fmaf calls)
-         "-ffp-contract=off", "-fno-gpu-rdc"]
+         "-ffp-contract=off",
+         # the SLP vectoriser pairs independent fp32 FMA chains into v_pk_fma_f32 and pays for it in
+         # v_mov shuffles and odd-sized LDS reads (measured: local-correlation D-stage 5x slower);
+         # where packed math pays (kde.hip) it is written explicitly with vector types
+         "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 
 def sources():

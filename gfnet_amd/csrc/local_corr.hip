@@ -41,10 +41,11 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunk = 16;                // channels staged per pass
 constexpr int kSlotV4 = kChunk / 4 + 1;   // float4s per staged pixel: 4 data + 1 pad = 80 B
-constexpr int kStageBytes = 72 * 1024;    // stage buffer (aliased by the D buffer in the epilogue)
+constexpr int kStageBytes = 68 * 1024;    // stage buffer (aliased by the D buffer in the epilogue)
 constexpr int kCapSlots = kStageBytes / (kSlotV4 * 16) - 1;  // pixels that fit, minus the zero slot
 static_assert((kCapSlots + 1) * kSlotV4 < 65536, "stage indices are packed in 16 bits");
 constexpr int kTileW = 16;
+constexpr int kMaxLds = 150 * 1024;       // dynamic LDS a tiled launch may ask for
 constexpr int kFar = 1 << 28;             // patch origin of a cell that samples nothing
 
 struct LcParams {
@@ -56,8 +57,10 @@ struct LcParams {
     int B, C, G, H, W;
     int tiles_x, tiles_y;
     float sqrt_c;
-    // general path only
-    int r, win_h, win_w, grid_based;
+    int r, win_h, win_w, grid_based;  // general path / flagged cells
+    float win_xhi, win_yhi;           // tiled path: linspace end points 2r/W, 2r/H rounded to fp32
+    int *todo;                        // [1 + B*tiles]: count, then ids of tiles left to the irregular launch
+    long todo_ints;
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
 #endif
@@ -89,7 +92,7 @@ __device__ __forceinline__ void lane_group(int lane, int &g, int &s) {
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * (float)size - 1.f) / 2.f; }
 
 // ---- general per-tap evaluation (mirrors the reference op for op) ---------------------------
-__device__ float tap_general(const LcParams &p, int b, int i, int j, int ky, int kx, int D, float nx, float ny) {
+__device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, int j, int ky, int kx, int D, float nx, float ny) {
     float ylo, yhi, xlo, xhi;
     if (p.grid_based) {
         ylo = (float)(-2.0 * p.r / p.G); yhi = (float)(2.0 * p.r / p.G);
@@ -152,41 +155,69 @@ __global__ __launch_bounds__(256) void local_corr_general_kernel(LcParams p) {
 }
 
 // ---- fast tiled kernel -----------------------------------------------------------------------
-template <int UN>  // wave-iterations in flight: all their loads are issued before the first LDS write
-__device__ __forceinline__ void stage_region(float4 *s4, const float *f1c, int H, int W, const Region &rg, int wave,
-                                             int lane) {
+// Stage traffic: wave-iteration wi covers channel group (wi & 3) of the 64 region pixels starting
+// at (wi >> 2) * 64: four coalesced row-segment loads (one per channel) and one 16-byte LDS write
+// per lane.  Issue and commit are separate so that a whole chunk's loads are in flight at once and
+// the NEXT chunk's loads stay in flight across the D-stage.  Addresses are clamped instead of
+// branched around (a conditional load becomes a branch + wait per element).
+template <int N>
+struct StageRegs {
+    float4 v[N];
+    int dst[N];  // float4 index in the stage, or -1
+};
+
+template <int N>
+__device__ __forceinline__ void stage_issue(StageRegs<N> &r, const float *f1c, int H, int W, const Region &rg, int wave,
+                                            int lane, int wi_begin) {
     const int npx = rg.w * rg.h;
-    const int nwi = ((npx + 63) >> 6) * 4;  // wave-iterations: 4 channel groups x runs of 64 pixels
+    const int nwi = ((npx + 63) >> 6) * 4;
     const float inv_w = 1.0f / (float)rg.w;
-    const size_t plane = (size_t)H * W;
-    for (int wi0 = wave; wi0 < nwi; wi0 += kWaves * UN) {
-        float4 v[UN];
-        int dst[UN];
+    const unsigned pl32 = (unsigned)(H * W);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int wi = wi0 + u * kWaves;
-            const int cg = wi & 3;
-            const int q = ((wi >> 2) << 6) + lane;
-            dst[u] = -1;
-            if (wi < nwi && q < npx) {
-                const int y = (int)(((float)q + 0.5f) * inv_w);  // exact for q < 2^16, w < 2^10
-                const int x = q - y * rg.w;
-                const float *src = f1c + (size_t)(cg * 4) * plane + (size_t)(rg.y0 + y) * W + (rg.x0 + x);
-                v[u].x = src[0];
-                v[u].y = src[plane];
-                v[u].z = src[2 * plane];
-                v[u].w = src[3 * plane];
-                dst[u] = (y * rg.pitch + x) * kSlotV4 + cg;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-            if (dst[u] >= 0) s4[dst[u]] = v[u];
+    for (int u = 0; u < N; ++u) {
+        const int wi = wi_begin + wave + u * kWaves;
+        const int cg = wi & 3;
+        const int q = ((wi >> 2) << 6) + lane;
+        const bool ok = (wi < nwi) & (q < npx);
+        const int y = (int)(((float)q + 0.5f) * inv_w);  // exact for q < 2^16, w < 2^10
+        const int x = q - y * rg.w;
+        // 32-bit element offsets from the wave-uniform chunk base (C*H*W < 2^31 is checked on the host):
+        // one VGPR per address instead of a 64-bit pair
+        const unsigned off = ok ? (unsigned)(cg * 4) * pl32 + (unsigned)((rg.y0 + y) * W + (rg.x0 + x)) : 0u;
+        const unsigned st = ok ? pl32 : 0u;
+        r.v[u].x = f1c[off];
+        r.v[u].y = f1c[off + st];
+        r.v[u].z = f1c[off + 2 * st];
+        r.v[u].w = f1c[off + 3 * st];
+        r.dst[u] = ok ? (y * rg.pitch + x) * kSlotV4 + cg : -1;
     }
 }
 
-template <int R, int ROUNDS>
-__global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p) {
+template <int N>
+__device__ __forceinline__ void stage_commit(float4 *s4, const StageRegs<N> &r) {
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        if (r.dst[u] >= 0) s4[r.dst[u]] = r.v[u];
+}
+
+// whatever of the region the first `done` wave-iterations per wave did not cover
+template <int N>
+__device__ __forceinline__ void stage_rest(float4 *s4, const float *f1c, int H, int W, const Region &rg, int wave, int lane,
+                                           int done) {
+    const int nwi = ((rg.w * rg.h + 63) >> 6) * 4;
+    for (int wi0 = done * kWaves; wi0 < nwi; wi0 += kWaves * N) {
+        StageRegs<N> r;
+        stage_issue(r, f1c, H, W, rg, wave, lane, wi0);
+        stage_commit(s4, r);
+    }
+}
+
+// One tile of 2*ROUNDS x 16 cells.
+//   STAGED = true : regular path -- the tile's windows are staged in LDS; a tile whose windows do
+//                   not fit is appended to p.todo and left to the second launch.
+//   STAGED = false: irregular path -- same arithmetic, patch pixels gathered straight from f1 (L2).
+template <int R, int ROUNDS, bool STAGED>
+__device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, unsigned char *smem) {
     constexpr int PW = 2 * R + 2;            // patch width: taps -R..R plus the +1 bilinear neighbour
     constexpr int P = PW * PW;               // patch positions per cell
     constexpr int NP = (P + 15) / 16;        // positions per lane
@@ -197,32 +228,58 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     constexpr int TS = 2 * D + 1;            // fraction-table cell stride (odd)
     static_assert((NC * DS + NC * TS) * 4 <= kStageBytes, "D buffer + fraction table must fit in the stage they alias");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *s4 = reinterpret_cast<float4 *>(smem);
     float *dbuf = reinterpret_cast<float *>(smem);
     int *cellX0 = reinterpret_cast<int *>(smem + kStageBytes);
     int *cellY0 = cellX0 + NC;
     float *cellNx = reinterpret_cast<float *>(cellY0 + NC);  // normalised centre (flow) of the cell
     float *cellNy = cellNx + NC;
-    int *bbox = reinterpret_cast<int *>(cellNy + NC);  // [ROUNDS][4] = x0,y0,x1,y1
-    int *cellSlow = bbox + ROUNDS * 4;                  // [NC] 1 = redo this cell with the per-tap routine
-    int *nSlow = cellSlow + NC;                         // number of such cells in the tile
-    float *tab = dbuf + NC * DS;                        // [NC][TS] per-tap fractions (aliases the stage)
+    int *cellSlow = reinterpret_cast<int *>(cellNy + NC);    // [NC] 1 = redo this cell with the per-tap routine
+    int *bbox = cellSlow + NC;                                // x0,y0,x1,y1 of the tile's windows
+    int *nSlow = bbox + 4;                                    // number of flagged cells in the tile
+    float *tab = dbuf + NC * DS;                              // [NC][TS] per-tap fractions (aliases the stage)
+    constexpr int kCellBytes = (NC * 20 + 16 + 16 + 15) & ~15;
+    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);  // [NC][C+4]: the tile's f0, cell-major
+    const int CS = p.C + 4;                                   // +4: the 4 cells a wave reads hit different banks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = wid / tiles;
     const int tile = wid - b * tiles;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int G = p.G, H = p.H, W = p.W;
 
-    // ---- per-cell setup: pixel coordinate, patch origin, bounding boxes ----------------------
-    if (tid < ROUNDS * 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
+    // ---- per-cell setup: patch origin, bounding box -------------------------------------------
+    if (tid < 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
     if (tid == 0) *nSlow = 0;
     __syncthreads();
-    const float xlo = (float)(-2.0 * R / W), xhi = (float)(2.0 * R / W);
-    const float ylo = (float)(-2.0 * R / H), yhi = (float)(2.0 * R / H);
+    const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;  // +-2r/W, +-2r/H as fp32
+    // the tile's f0 block (NC cells x C channels, 8-16 KB): coalesced 64-byte row segments -> LDS,
+    // cell-major.  (Loading f0 per lane would issue 16 loads per round and chunk that fetch 16 bytes each.)
+    {
+        const float *f0b = p.f0 + (size_t)b * p.f0_bs;
+        const int total = p.C * NC;
+        constexpr int UF = 4;
+        for (int e0 = tid; e0 < total; e0 += kThreads * UF) {
+            float v[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int e = e0 + q * kThreads;
+                const int c = e / NC, cell = e - c * NC;
+                const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
+                const bool ok = (e < total) & (gi < G) & (gj < G) & !ABL(p, 4);
+                v[q] = f0b[ok ? (size_t)c * G * G + (size_t)gi * G + gj : 0];  // clamped address, select below
+                v[q] = ok ? v[q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int e = e0 + q * kThreads;
+                const int c = e / NC, cell = e - c * NC;
+                if (e < total) f0s[cell * CS + c] = v[q];
+            }
+        }
+    }
+    int bx0 = kFar, by0 = kFar, bx1 = -kFar, by1 = -kFar;  // this cell's window clipped to the image
     if (tid < NC) {
         const int ci = tid >> 4, cj = tid & 15;
         const int gi = ty * TH + ci, gj = tx * kTileW + cj;
@@ -230,20 +287,16 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         float nx = 0.f, ny = 0.f;
         if (gi < G && gj < G) {
             cell_coords(p, b, gi, gj, nx, ny);
-            // patch origin = floor of the reference's own fp32 coordinate of tap 0, minus nothing:
+            // patch origin = floor of the reference's own fp32 coordinate of tap 0:
             // taps kx=0..2R then read columns kx and kx+1 of the patch
             const float fx = floorf(unnorm(nx + gfn::linspace_at(xlo, xhi, D, 0), W));
             const float fy = floorf(unnorm(ny + gfn::linspace_at(ylo, yhi, D, 0), H));
             if ((fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f)) {  // false for nan/inf
                 X0 = (int)fx;
                 Y0 = (int)fy;
-                const int x0 = max(X0, 0), x1 = min(X0 + PW, W), y0 = max(Y0, 0), y1 = min(Y0 + PW, H);
-                if (x0 < x1 && y0 < y1) {
-                    int *bb = bbox + (tid >> 5) * 4;
-                    atomicMin(bb + 0, x0);
-                    atomicMin(bb + 1, y0);
-                    atomicMax(bb + 2, x1);
-                    atomicMax(bb + 3, y1);
+                if (STAGED) {
+                    const int x0 = max(X0, 0), x1 = min(X0 + PW, W), y0 = max(Y0, 0), y1 = min(Y0 + PW, H);
+                    if (x0 < x1 && y0 < y1) { bx0 = x0; by0 = y0; bx1 = x1; by1 = y1; }
                 }
             } else {
                 slow = 1;  // non-finite / absurd flow: let the per-tap routine decide
@@ -256,106 +309,144 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         cellNy[tid] = ny;
         cellSlow[tid] = slow;
     }
-    // the zero slot (index kCapSlots) is what every out-of-image tap reads
-    if (tid < kSlotV4) s4[kCapSlots * kSlotV4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // ---- choose the staging regions (block-uniform) -------------------------------------------
-    Region reg[ROUNDS];
-    bool fit[ROUNDS];
-    bool whole;
-    {
-        int ux0 = kFar, uy0 = kFar, ux1 = -kFar, uy1 = -kFar;
+    if (STAGED && wave < (NC + 63) / 64) {  // bounding box: reduce inside the wave (all 64 lanes take
+        // part, idle ones with the identity), then one LDS atomic per wave and bound
 #pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int x0 = bbox[rd * 4 + 0], y0 = bbox[rd * 4 + 1], x1 = bbox[rd * 4 + 2], y1 = bbox[rd * 4 + 3];
-            ux0 = min(ux0, x0); uy0 = min(uy0, y0); ux1 = max(ux1, x1); uy1 = max(uy1, y1);
-            Region r;
-            r.x0 = x0; r.y0 = y0;
-            r.w = max(x1 - x0, 0); r.h = max(y1 - y0, 0);
-            r.pitch = r.w + ((PW - r.w) & 15);
-            reg[rd] = r;
-            fit[rd] = (long)r.pitch * r.h <= kCapSlots;
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
+            bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
         }
-        Region u;
-        u.x0 = ux0; u.y0 = uy0;
-        u.w = max(ux1 - ux0, 0); u.h = max(uy1 - uy0, 0);
-        u.pitch = u.w + ((PW - u.w) & 15);
-        whole = (long)u.pitch * u.h <= kCapSlots;
-        if (whole) {
-#pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) { reg[rd] = u; fit[rd] = true; }
+        if (lane == 0) {
+            atomicMin(bbox + 0, bx0);
+            atomicMin(bbox + 1, by0);
+            atomicMax(bbox + 2, bx1);
+            atomicMax(bbox + 3, by1);
         }
     }
+    // the zero slot (index kCapSlots) is what every out-of-image tap reads
+    if (STAGED && tid < kSlotV4) s4[kCapSlots * kSlotV4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 
-    // ---- per-lane D-stage addressing -------------------------------------------------------
+    // ---- the staging region (block-uniform) -----------------------------------------------------
+    Region u;
+    u.x0 = bbox[0]; u.y0 = bbox[1];
+    u.w = max(bbox[2] - u.x0, 0); u.h = max(bbox[3] - u.y0, 0);
+    u.pitch = u.w + ((PW - u.w) & 15);
+    if (STAGED && (long)u.pitch * u.h > kCapSlots) {
+        // strong magnification / rotation / scattered flow: the windows do not fit the stage
+        if (tid == 0) p.todo[1 + atomicAdd(p.todo, 1)] = (int)wid;
+        return;
+    }
+
+    // ---- per-lane D-stage addressing -----------------------------------------------------------
     int g, s16;
     lane_group(lane, g, s16);
     const int cr = wave * 4 + g;  // cell inside a round (0..31): row cr>>4, column cr&15
-    unsigned apk[ROUNDS][(NP + 1) / 2];  // float4 index (< 2^16) of each (round, pass) patch pixel, two per register
+    unsigned apk[ROUNDS][(NP + 1) / 2];  // staged: float4 index (< 2^16) of each (round, pass) patch pixel, two per register
     float acc[ROUNDS][NP];
-    const float *f0c[ROUNDS];     // this lane's f0 column (channel stride G*G), or null
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
         const int X0 = cellX0[cell], Y0 = cellY0[cell];
-        const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-        f0c[rd] = (gi < G && gj < G) ? p.f0 + (size_t)b * p.f0_bs + (size_t)gi * G + gj : nullptr;
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
-            const int pp = s16 + 16 * t;
-            const int yy = pp / PW, xx = pp - yy * PW;
-            const int X = X0 + xx, Y = Y0 + yy;
-            const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
-            const int slot = in ? (Y - reg[rd].y0) * reg[rd].pitch + (X - reg[rd].x0) : kCapSlots;
-            const unsigned a = (unsigned)(slot * kSlotV4);
-            if (t & 1)
-                apk[rd][t >> 1] |= a << 16;
-            else
-                apk[rd][t >> 1] = a;
             acc[rd][t] = 0.f;
+            if (STAGED) {
+                const int pp = s16 + 16 * t;
+                const int yy = pp / PW, xx = pp - yy * PW;
+                const int X = X0 + xx, Y = Y0 + yy;
+                const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
+                const int slot = in ? (Y - u.y0) * u.pitch + (X - u.x0) : kCapSlots;
+                const unsigned a = (unsigned)(slot * kSlotV4);
+                if (t & 1)
+                    apk[rd][t >> 1] |= a << 16;
+                else
+                    apk[rd][t >> 1] = a;
+            }
         }
     }
 
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
     const float *f1b = p.f1 + (size_t)b * p.C * H * W;
-    constexpr int UN = (ROUNDS * NP >= 32) ? 1 : ((ROUNDS * NP >= 24 || ROUNDS > 2) ? 2 : 4);
+    constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
+    StageRegs<PRE> pre;
+    if (STAGED && !ABL(p, 1)) {
+        stage_issue(pre, f1b, H, W, u, wave, lane, 0);
+        stage_commit(s4, pre);
+        stage_rest<2>(s4, f1b, H, W, u, wave, lane, PRE);
+    }
+    if (STAGED) __syncthreads();
     for (int c0 = 0; c0 < p.C; c0 += kChunk) {
-        // keep the packed indices packed: without this the unpacking is hoisted out of the loop and
-        // the unpacked copies cost NP more registers per round (spills at r = 6, 7)
+        const float *f1c = f1b + (size_t)c0 * H * W;
+        const bool more = c0 + kChunk < p.C;
+        if (STAGED) {
+            // keep the packed indices packed: without this the unpacking is hoisted out of the loop and
+            // the unpacked copies cost NP more registers per round
 #pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd)
+            for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-            for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));
-        if (whole) {  // the usual case: one stage per channel chunk serves every round
-            __syncthreads();  // everyone is done reading the previous contents
-            if (!ABL(p, 1)) stage_region<UN>(s4, f1b + (size_t)c0 * H * W, H, W, reg[0], wave, lane);
-            __syncthreads();
+                for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));
+            // next chunk's loads: in flight across this chunk's D-stage
+            if (more && !ABL(p, 1)) stage_issue(pre, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, 0);
         }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (!fit[rd]) continue;
             float f[kChunk];
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k) f[k] = (f0c[rd] && !ABL(p, 4)) ? f0c[rd][(size_t)(c0 + k) * cs] : 0.f;
-            if (!whole) {
-                __syncthreads();
-                if (!ABL(p, 1)) stage_region<1>(s4, f1b + (size_t)c0 * H * W, H, W, reg[rd], wave, lane);
-                __syncthreads();
+            {   // this lane's cell, 16 channels: 4 LDS reads (the 16 lanes of a cell read the same address)
+                const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + c0);
+                const float4 a0 = fq[0], a1 = fq[1], a2 = fq[2], a3 = fq[3];
+                f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+                f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w; f[12] = a3.x; f[13] = a3.y; f[14] = a3.z; f[15] = a3.w;
             }
             if (ABL(p, 2)) continue;
+            if (STAGED) {
 #pragma unroll
-            for (int t = 0; t < NP; ++t) {
-                const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
-                const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-                float a = acc[rd][t];
-                a = fmaf(f[0], v0.x, a);  a = fmaf(f[1], v0.y, a);  a = fmaf(f[2], v0.z, a);  a = fmaf(f[3], v0.w, a);
-                a = fmaf(f[4], v1.x, a);  a = fmaf(f[5], v1.y, a);  a = fmaf(f[6], v1.z, a);  a = fmaf(f[7], v1.w, a);
-                a = fmaf(f[8], v2.x, a);  a = fmaf(f[9], v2.y, a);  a = fmaf(f[10], v2.z, a); a = fmaf(f[11], v2.w, a);
-                a = fmaf(f[12], v3.x, a); a = fmaf(f[13], v3.y, a); a = fmaf(f[14], v3.z, a); a = fmaf(f[15], v3.w, a);
-                acc[rd][t] = a;
+                for (int t = 0; t < NP; ++t) {
+                    const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
+                    const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                    float a = acc[rd][t];
+                    a = fmaf(f[0], v0.x, a);  a = fmaf(f[1], v0.y, a);  a = fmaf(f[2], v0.z, a);  a = fmaf(f[3], v0.w, a);
+                    a = fmaf(f[4], v1.x, a);  a = fmaf(f[5], v1.y, a);  a = fmaf(f[6], v1.z, a);  a = fmaf(f[7], v1.w, a);
+                    a = fmaf(f[8], v2.x, a);  a = fmaf(f[9], v2.y, a);  a = fmaf(f[10], v2.z, a); a = fmaf(f[11], v2.w, a);
+                    a = fmaf(f[12], v3.x, a); a = fmaf(f[13], v3.y, a); a = fmaf(f[14], v3.z, a); a = fmaf(f[15], v3.w, a);
+                    acc[rd][t] = a;
+                }
+            } else {
+                const size_t plane = (size_t)H * W;
+                const int cX0 = cellX0[rd * 32 + cr], cY0 = cellY0[rd * 32 + cr];
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    const int pp = s16 + 16 * t;
+                    const int yy = pp / PW, xx = pp - yy * PW;
+                    const int X = cX0 + xx, Y = cY0 + yy;
+                    const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
+                    const float *src = f1c + (in ? (size_t)Y * W + X : 0);  // offset 0 when outside: valid memory, masked below
+                    float v[kChunk];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) v[k] = src[k * plane];
+                    float a = acc[rd][t];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) a = fmaf(f[k], in ? v[k] : 0.f, a);
+                    acc[rd][t] = a;
+                    __builtin_amdgcn_sched_barrier(0);  // one pass of loads in flight at a time (register budget)
+                }
             }
+        }
+        // do not let the scheduler sink this chunk's FMAs below the barrier (it would keep every
+        // LDS read result of the chunk live across it: hundreds of spills)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+            for (int t = 0; t < NP; ++t) asm volatile("" : "+v"(acc[rd][t]));  // pins the FMAs above this point
+        if (STAGED && more) {
+            __syncthreads();  // everyone is done reading this chunk
+            if (!ABL(p, 1)) {
+                stage_commit(s4, pre);
+                stage_rest<2>(s4, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, PRE);
+            }
+            __syncthreads();
         }
     }
 
@@ -390,52 +481,65 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     }
     __syncthreads();
     {
-        constexpr int NCB = NC / 64;      // 64-cell blocks per tile
-        constexpr int WPB = kWaves / NCB;  // waves sharing one block of cells
-        const int cell = (wave / WPB) * 64 + lane;
-        const int rd = cell >> 5;
+        // each wave combines CW cells x a strided subset of the K taps: lane -> cell (so that stores run
+        // along the grid row), taps strided over the waves (and over lane halves when NC == 32)
+        constexpr int CW = NC >= 64 ? 64 : 32;          // cells per wave-instruction
+        constexpr int NCB = NC / CW;                    // groups of CW cells per tile
+        constexpr int WPB = kWaves / NCB * (64 / CW);   // tap phases sharing one group of cells
+        const int cell = (wave / (kWaves / NCB)) * CW + (lane & (CW - 1));
+        const int kphase = (wave % (kWaves / NCB)) * (64 / CW) + (lane / CW);
         const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-        bool fast = false;
-#pragma unroll
-        for (int q = 0; q < ROUNDS; ++q) fast |= (q == rd) & fit[q];
-        if (fast && gi < G && gj < G && !cellSlow[cell] && !ABL(p, 8)) {
+        if (gi < G && gj < G && !cellSlow[cell] && !ABL(p, 8)) {
             const float *dc = dbuf + cell * DS;
             const float *tc = tab + cell * TS;
             float *o = p.out + (size_t)b * p.out_bs + (size_t)gi * G + gj;
-            for (int k = wave % WPB; k < K; k += WPB) {
-                const int ky = k / D, kx = k - ky * D;
-                const float wx1 = tc[kx], wy1 = tc[D + ky];
-                const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                const float *d = dc + ky * PW + kx;
-                // corner order and weights as grid_sample: nw, ne, sw, se
-                float v = d[0] * (wx0 * wy0);
-                v += d[1] * (wx1 * wy0);
-                v += d[PW] * (wx0 * wy1);
-                v += d[PW + 1] * (wx1 * wy1);
-                o[(size_t)k * cs] = v / p.sqrt_c;
+            constexpr int NK = (K + WPB - 1) / WPB;
+#pragma unroll 4
+            for (int n = 0; n < NK; ++n) {  // constant trip count: the LDS reads of several taps overlap
+                const int k = kphase + n * WPB;
+                if (k < K) {
+                    const int ky = k / D, kx = k - ky * D;
+                    const float wx1 = tc[kx], wy1 = tc[D + ky];
+                    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                    const float *d = dc + ky * PW + kx;
+                    // corner order and weights as grid_sample: nw, ne, sw, se
+                    float v = d[0] * (wx0 * wy0);
+                    v += d[1] * (wx1 * wy0);
+                    v += d[PW] * (wx0 * wy1);
+                    v += d[PW + 1] * (wx1 * wy1);
+                    o[(size_t)k * cs] = v / p.sqrt_c;
+                }
             }
         }
     }
 
-    // ---- what the tiled path could not do: whole rounds whose windows did not fit the stage, and
-    //      single cells flagged above.  General per-tap routine, same launch. ----------------------
-    bool any_slow = *nSlow != 0;
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) any_slow |= !fit[rd];
-    if (any_slow) {  // block-uniform, rare
-        LcParams q = p;
-        q.r = R; q.win_h = H; q.win_w = W; q.grid_based = 0;
-        for (int cell = 0; cell < NC && !ABL(p, 16); ++cell) {
-            bool slow = cellSlow[cell] != 0;
-#pragma unroll
-            for (int rd = 0; rd < ROUNDS; ++rd) slow |= ((cell >> 5) == rd) & !fit[rd];
-            if (!slow) continue;  // block-uniform
+    // ---- flagged cells: general per-tap routine (about one cell in 10^4) ------------------------
+    if (*nSlow != 0 && !ABL(p, 16)) {  // block-uniform, rare
+        for (int cell = 0; cell < NC; ++cell) {
+            if (!cellSlow[cell]) continue;
             const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
             if (gi >= G || gj >= G) continue;
             for (int k = tid; k < K; k += kThreads)
                 p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
-                    tap_general(q, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
+                    tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
         }
+    }
+}
+
+template <int R, int ROUNDS>
+__global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    process_tile<R, ROUNDS, true>(p, gfn::xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// second launch: the tiles the staged kernel left in p.todo (their number is only known on the device)
+template <int R, int ROUNDS>
+__global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = p.todo[0];
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        process_tile<R, ROUNDS, false>(p, (unsigned)p.todo[1 + it], smem);
+        __syncthreads();  // LDS is reused by the next tile
     }
 }
 
@@ -445,23 +549,44 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
     p.tiles_y = (p.G + 2 * ROUNDS - 1) / (2 * ROUNDS);
-    const size_t lds = kStageBytes + NC * 20 + ROUNDS * 16 + 16;
+    p.r = R; p.win_h = p.H; p.win_w = p.W; p.grid_based = 0;  // what tap_general needs for flagged cells
+    p.win_xhi = (float)(2.0 * R / p.W);
+    p.win_yhi = (float)(2.0 * R / p.H);
+    const size_t lds = kStageBytes + ((NC * 20 + 16 + 16 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
+    // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
+    // one workgroup per CU; absurdly wide features go to the general kernel
+    if (lds > kMaxLds) return -1000;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         attr_set = true;
     }
-    const unsigned grid = (unsigned)p.B * p.tiles_x * p.tiles_y;
-    hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(grid), dim3(kThreads), lds, stream, p);
-    return gfn::check_launch("local_corr_tile_kernel");
+    const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
+    if ((size_t)p.todo_ints < (size_t)total + 1) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
+    if (hipMemsetAsync(p.todo, 0, sizeof(int), stream) != hipSuccess) return gfn::fail(GFN_ERR_LAUNCH, "local_corr: memset failed");
+    hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(total), dim3(kThreads), lds, stream, p);
+    if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
+    const unsigned grid2 = total < 512 ? total : 512;
+    hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS>), dim3(grid2), dim3(kThreads), lds, stream, p);
+    return gfn::check_launch("local_corr_irregular_kernel");
 }
 
 }  // namespace
 
+// ints of scratch the tiled path wants: the list of tiles left to the irregular launch.
+GFN_EXPORT int64_t gfn_local_corr_scratch_bytes(int B, int G) {
+    // smallest tile is 2 x 16 cells -> at most B * ceil(G/2) * ceil(G/16) tiles, plus the counter
+    const int64_t tiles = (int64_t)((G + 1) / 2) * ((G + 15) / 16);
+    return 4 * ((int64_t)B * tiles + 1);
+}
+
 GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
                                      int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based,
-                                     int win_h, int win_w, int variant, gfn_stream_t stream) {
+                                     int win_h, int win_w, int variant, void *scratch, int64_t scratch_bytes,
+                                     gfn_stream_t stream) {
     if (!f0 || !f1 || !out) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: null tensor pointer");
     if (B < 0 || C <= 0 || G <= 0 || H <= 0 || W <= 0 || r < 0 || win_h <= 0 || win_w <= 0)
         return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: bad size B=%d C=%d G=%d H=%d W=%d r=%d", B, C, G, H, W, r);
@@ -482,22 +607,28 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     p.tiles_x = p.tiles_y = 0;
     p.sqrt_c = (float)sqrt((double)C);
     p.r = r; p.win_h = win_h; p.win_w = win_w; p.grid_based = grid_based;
+    p.todo = reinterpret_cast<int *>(scratch);
+    p.todo_ints = scratch ? scratch_bytes / 4 : 0;
 #ifdef GFN_ABLATE
     p.dbg = variant >> 8;
     variant &= 0xff;
 #endif
 
-    const bool fast_ok = variant == 0 && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7;
+    // the tiled path needs the tile list in scratch; without it the general kernel still gives the right answer
+    const bool fast_ok = variant == 0 && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7 &&
+                         scratch && scratch_bytes >= gfn_local_corr_scratch_bytes(B, G) && ((uintptr_t)scratch & 3) == 0;
     if (fast_ok) {
+        int rc = -1000;
         switch (r) {
-            case 1: return launch_tile<1, 4>(p, s);
-            case 2: return launch_tile<2, 4>(p, s);
-            case 3: return launch_tile<3, 2>(p, s);
-            case 4: return launch_tile<4, 2>(p, s);
-            case 5: return launch_tile<5, 2>(p, s);
-            case 6: return launch_tile<6, 2>(p, s);
-            case 7: return launch_tile<7, 2>(p, s);
+            case 1: rc = launch_tile<1, 4>(p, s); break;
+            case 2: rc = launch_tile<2, 4>(p, s); break;
+            case 3: rc = launch_tile<3, 2>(p, s); break;
+            case 4: rc = launch_tile<4, 2>(p, s); break;
+            case 5: rc = launch_tile<5, 1>(p, s); break;
+            case 6: rc = launch_tile<6, 1>(p, s); break;
+            case 7: rc = launch_tile<7, 1>(p, s); break;
         }
+        if (rc != -1000) return rc;  // -1000: shape not supported by the tiled path
     }
     const long total = (long)B * K * G * G;
     const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -507,9 +638,9 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
 
 GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
                                   int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
-                                  int win_w, gfn_stream_t stream) {
-    return gfn_local_corr_fwd_ex(f0, f0_bs, f1, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0,
-                                 stream);
+                                  int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream) {
+    return gfn_local_corr_fwd_ex(f0, f0_bs, f1, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0, scratch,
+                                 scratch_bytes, stream);
 }
 
 namespace {

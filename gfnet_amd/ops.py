@@ -92,9 +92,12 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
                                      float(40 / 32 * scale_factor), st), "gfn_refiner_input_fwd")
     if corr_in_other:
         out = d[:, 2 * C + Dd:]
+        nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
+        scr = _lib.scratch(dev, nscr)
         check(_timed(f"local_corr_c{C}_h{Hs}_g{G}_r{r}",
                      lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(fl), c_vp(out.data_ptr()), CH * G * G,
-                                                     B, C, G, Hs, Ws, r, 0, Hs, Ws, st)), "gfn_local_corr_fwd")
+                                                     B, C, G, Hs, Ws, r, 0, Hs, Ws, ptr(scr), nscr, st)),
+              "gfn_local_corr_fwd")
     return d
 
 

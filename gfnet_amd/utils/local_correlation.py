@@ -62,12 +62,14 @@ def local_correlation(featuremap_size, feature0, feature1, local_radius, num_gri
         out_bs = out.stride(0) if B > 1 else K * G * G
     L = _lib.lib()
     st = _lib.stream_ptr(dev)
+    nscr = int(L.gfn_local_corr_scratch_bytes(B, G))
+    scr = _lib.scratch(dev, nscr)
     hh, ww = h, w
     for level in range(int(num_level)):
         o = res[:, level * K1:(level + 1) * K1]
         _lib.check(L.gfn_local_corr_fwd_ex(_lib.ptr(f0), f0_bs, _lib.ptr(f1), _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
                                            out_bs, B, c, G, hh, ww, r, 1 if grid_based_correlation else 0, h, w,
-                                           int(_variant), st), "gfn_local_corr_fwd")
+                                           int(_variant), _lib.ptr(scr), nscr, st), "gfn_local_corr_fwd")
         if level + 1 < num_level:
             pooled = torch.empty((B, c, hh // 2, ww // 2), device=dev, dtype=torch.float32)
             _lib.check(L.gfn_avg_pool2(_lib.ptr(f1), _lib.ptr(pooled), B * c, hh, ww, st), "gfn_avg_pool2")

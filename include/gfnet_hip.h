@@ -60,19 +60,21 @@ int gfn_device_arch(char *buf, int buflen);
  *   out  (B,K,G,G)  batch stride out_bs floats (>= K*G*G), K = (2r+1)^2
  *
  * Fast path (LDS-tiled, shared bilinear fractions): C % 16 == 0, 1 <= r <= 7, !grid_based,
- * win_h == H, win_w == W.  Anything else runs the general per-tap kernel.  Flow values are
- * unrestricted (out-of-image taps read zeros); tiles whose search windows do not fit the LDS
- * stage fall back to the per-tap path inside the same launch.
+ * win_h == H, win_w == W, and `scratch` (device memory, gfn_local_corr_scratch_bytes(B, G) bytes,
+ * 4-byte aligned; holds the list of tiles whose search windows do not fit the LDS stage and are
+ * finished by a second, gather-based launch).  Anything else -- including scratch == NULL -- runs
+ * the general per-tap kernel.  Flow values are unrestricted (out-of-image taps read zeros).
  */
+int64_t gfn_local_corr_scratch_bytes(int B, int G);
 int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out, int64_t out_bs,
-                       int B, int C, int G, int H, int W, int r, int grid_based, int win_h, int win_w,
-                       gfn_stream_t stream);
+                       int B, int C, int G, int H, int W, int r, int grid_based, int win_h, int win_w, void *scratch,
+                       int64_t scratch_bytes, gfn_stream_t stream);
 
 /* Variant selector for experiments/tests: 0 = auto (as above), 1 = force the general per-tap
  * kernel.  Same arguments otherwise. */
 int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
                           int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
-                          int win_w, int variant, gfn_stream_t stream);
+                          int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
 /* F.avg_pool2d(x, 2, 2) between correlation levels (utils/local_correlation.py:71).
  * in (BC,H,W) -> out (BC,H/2,W/2). */
