@@ -17,13 +17,13 @@ c_int, c_i64, c_vp, c_float, c_double = ctypes.c_int, ctypes.c_int64, ctypes.c_v
 
 # name -> argtypes; every entry point returns int (GFN_OK or a negative error code)
 _SIGNATURES = {
-    "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp, c_i64, c_vp],
-    "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp, c_i64, c_vp],
+    "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp, c_i64, c_vp],
+    "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp, c_i64, c_vp],
     "gfn_avg_pool2": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
-    "gfn_corr_softargmax_fwd": [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
+    "gfn_corr_softargmax_fwd": [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_corr_volume_fwd": [c_vp, c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
     "gfn_pos_embed_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
-    "gfn_refiner_input_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_vp],
+    "gfn_refiner_input_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_vp],
     "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
     "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_flow_update_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],

@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int KS, bool WRITE_VOL, bool WRITE_FLOW>
 __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
                                                               float *__restrict__ vol, float *__restrict__ flow, int B,
-                                                              int C, int H0, int W0, int H1, int W1, float sqrt_c) {
+                                                              int Bh, int C, int H0, int W0, int H1, int W1, float sqrt_c) {
     const int N0 = H0 * W0, N1 = H1 * W1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int itiles = (N0 + 31) >> 5;
@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__res
     const int i = i0 + col;
     const int ic = min(i, N0 - 1);
 
-    const float *f0b = f0 + (size_t)b * C * N0;
-    const float *f1b = f1 + (size_t)b * C * N1;
+    // symmetric batches are virtual (Bh = B/2 images per side): direction b >= Bh swaps the roles of
+    // the two feature arrays instead of reading a concatenated copy (model/network.py:213-222)
+    const float *f0b = b < Bh ? f0 + (size_t)b * C * N0 : f1 + (size_t)(b - Bh) * C * N0;
+    const float *f1b = b < Bh ? f1 + (size_t)b * C * N1 : f0 + (size_t)(b - Bh) * C * N1;
 
     // B operand: this wave's 32 columns of f0, all channels, kept in registers
     float bop[KS];
@@ -145,30 +147,32 @@ int check_args(const void *f0, const void *f1, int B, int C, int H0, int W0, int
 }
 
 template <bool WV, bool WF>
-int launch_corr(const float *f0, const float *f1, float *vol, float *flow, int B, int C, int H0, int W0, int H1, int W1,
-                hipStream_t stream) {
+int launch_corr(const float *f0, const float *f1, float *vol, float *flow, int B, int Bh, int C, int H0, int W0, int H1,
+                int W1, hipStream_t stream) {
     const int waves = B * ((H0 * W0 + 31) / 32);
     const dim3 grid((waves + 3) / 4), block(256);
     const float sc = (float)sqrt((double)C);
     if (C <= 16)
-        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else if (C <= 32)
-        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else if (C <= 64)
-        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else
-        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     return gfn::check_launch("corr_softargmax_kernel");
 }
 
 }  // namespace
 
 GFN_EXPORT int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B, int C, int H0, int W0,
-                                       int H1, int W1, gfn_stream_t stream) {
+                                       int H1, int W1, int symmetric, gfn_stream_t stream) {
     if (int e = check_args(f0, f1, B, C, H0, W0, H1, W1)) return e;
     if (!flow) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: null flow");
+    if (symmetric && ((B & 1) || H0 != H1 || W0 != W1))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: symmetric needs an even batch and equal map sizes");
     if (B == 0) return GFN_OK;
-    return launch_corr<false, true>(f0, f1, nullptr, flow, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+    return launch_corr<false, true>(f0, f1, nullptr, flow, B, symmetric ? B / 2 : B, C, H0, W0, H1, W1, (hipStream_t)stream);
 }
 
 GFN_EXPORT int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C,
@@ -176,8 +180,8 @@ GFN_EXPORT int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol,
     if (int e = check_args(f0, f1, B, C, H0, W0, H1, W1)) return e;
     if (!vol) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_volume: null volume");
     if (B == 0) return GFN_OK;
-    if (flow_or_null) return launch_corr<true, true>(f0, f1, vol, flow_or_null, B, C, H0, W0, H1, W1, (hipStream_t)stream);
-    return launch_corr<true, false>(f0, f1, vol, nullptr, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+    if (flow_or_null) return launch_corr<true, true>(f0, f1, vol, flow_or_null, B, B, C, H0, W0, H1, W1, (hipStream_t)stream);
+    return launch_corr<true, false>(f0, f1, vol, nullptr, B, B, C, H0, W0, H1, W1, (hipStream_t)stream);
 }
 
 GFN_EXPORT int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1,

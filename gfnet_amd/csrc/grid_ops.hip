@@ -52,35 +52,82 @@ __device__ __forceinline__ float bilin_fetch(const float *pl, int W, const Bilin
     return v;
 }
 
-__global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+// Clamped form of a bilinear set-up: four always-valid offsets and four weights that are zero for
+// out-of-image corners, so the gathers need no branches (a zero weight times any finite value adds
+// an exact 0; corner order nw, ne, sw, se is kept).
+struct BilinC {
+    int o[4];
+    float w[4];
+};
+
+__device__ __forceinline__ BilinC bilin_clamped(float gx, float gy, int W, int H) {
+    const Bilin s = bilin_setup(gx, gy, W, H);
+    BilinC c;
+    const int o00 = s.y0 * W + s.x0;
+    c.o[0] = (s.ya & s.xa) ? o00 : 0;
+    c.o[1] = (s.ya & s.xb) ? o00 + 1 : 0;
+    c.o[2] = (s.yb & s.xa) ? o00 + W : 0;
+    c.o[3] = (s.yb & s.xb) ? o00 + W + 1 : 0;
+    c.w[0] = (s.ya & s.xa) ? s.w00 : 0.f;
+    c.w[1] = (s.ya & s.xb) ? s.w01 : 0.f;
+    c.w[2] = (s.yb & s.xa) ? s.w10 : 0.f;
+    c.w[3] = (s.yb & s.xb) ? s.w11 : 0.f;
+    return c;
+}
+
+// One thread per (direction, grid cell): both bilinear set-ups once, then the channels in groups of
+// 8 with all 32 gathers of a group in flight; stores run along the grid row for every channel.
+// Symmetric batches are virtual: direction b < Bh queries image A[b] against B[b], direction
+// b >= Bh queries B[b-Bh] against A[b-Bh] (the reference concatenates the pyramids instead,
+// model/network.py:213-222).
+__global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restrict__ fa, const float *__restrict__ fb,
                                                             const float *__restrict__ flow, const float *__restrict__ dw,
                                                             const float *__restrict__ db, float *__restrict__ d, long d_bs,
-                                                            int B, int C, int Hs, int Ws, int G, int Dd, float disp_scale) {
-    const int CH = 2 * C + Dd;
-    const long total = (long)B * CH * G * G;
+                                                            int B, int Bh, int C, int Hs, int Ws, int G, int Dd,
+                                                            float disp_scale) {
+    const long total = (long)B * G * G;
     const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
+    const size_t plane = (size_t)Hs * Ws, GG = (size_t)G * G;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % G);
-        long t = idx / G;
+        const long t = idx / G;
         const int i = (int)(t % G);
-        t /= G;
-        const int ch = (int)(t % CH);
-        const int b = (int)(t / CH);
+        const int b = (int)(t / G);
+        const float *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
+        const float *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
         const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
         const float fx = flow[(((size_t)b * 2 + 0) * G + i) * G + j], fy = flow[(((size_t)b * 2 + 1) * G + i) * G + j];
-        float v;
-        if (ch < C) {  // grid_feature = grid_sample(x, im_A_coords)            network.py:547
-            const Bilin s = bilin_setup(cx, cy, Ws, Hs);
-            v = bilin_fetch(f0 + ((size_t)b * C + ch) * Hs * Ws, Ws, s);
-        } else if (ch < 2 * C) {  // x_hat = grid_sample(y, flow)               network.py:537
-            const Bilin s = bilin_setup(fx, fy, Ws, Hs);
-            v = bilin_fetch(f1 + ((size_t)b * C + (ch - C)) * Hs * Ws, Ws, s);
-        } else {  // disp_emb(40/32 * scale_factor * (flow - im_A_coords))       network.py:548-549
-            const int o = ch - 2 * C;
-            const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
-            v = dw[o * 2 + 0] * dx + dw[o * 2 + 1] * dy + db[o];
+        const BilinC sa = bilin_clamped(cx, cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
+        const BilinC sb = bilin_clamped(fx, fy, Ws, Hs);  // x_hat = grid_sample(y, flow)                 network.py:537
+        float *o = d + (size_t)b * d_bs + (size_t)i * G + j;
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float va[8][4], vb[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t pl = (size_t)min(c0 + k, C - 1) * plane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    va[k][e] = q[pl + sa.o[e]];
+                    vb[k][e] = sm[pl + sb.o[e]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (c0 + k < C) {
+                    float ra = 0.f, rb = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ra += va[k][e] * sa.w[e];
+                        rb += vb[k][e] * sb.w[e];
+                    }
+                    o[(size_t)(c0 + k) * GG] = ra;
+                    o[(size_t)(C + c0 + k) * GG] = rb;
+                }
+            }
         }
-        d[(size_t)b * d_bs + ((size_t)ch * G + i) * G + j] = v;
+        // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
+        const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
+        for (int k = 0; k < Dd; ++k) o[(size_t)(2 * C + k) * GG] = dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k];
     }
 }
 
@@ -194,15 +241,16 @@ inline unsigned grid_for(long total, int cap = 16384) {
 
 GFN_EXPORT int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w,
                                      const float *disp_b, float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G,
-                                     int disp_dim, float disp_scale, gfn_stream_t stream) {
+                                     int disp_dim, float disp_scale, int symmetric, gfn_stream_t stream) {
     if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b)))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: null pointer");
-    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G)
+    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G ||
+        (symmetric && (B & 1)) || (long)C * Hs * Ws >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
     if (B == 0) return GFN_OK;
-    const long total = (long)B * (2 * C + disp_dim) * G * G;
+    const long total = (long)B * G * G;
     hipLaunchKernelGGL(refiner_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, f0, f1, flow, disp_w,
-                       disp_b, d, (long)d_bs, B, C, Hs, Ws, G, disp_dim, disp_scale);
+                       disp_b, d, (long)d_bs, B, symmetric ? B / 2 : B, C, Hs, Ws, G, disp_dim, disp_scale);
     return gfn::check_launch("refiner_input_kernel");
 }
 

@@ -56,32 +56,47 @@ __device__ bool draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t N, u
     return true;
 }
 
+// value of `v` in lane `srclane`.  UNIFORM: srclane is wave-uniform -> two v_readlane_b32 (a few
+// cycles); otherwise a general shuffle (ds_bpermute, LDS crossbar latency).
+template <bool UNIFORM>
+__device__ __forceinline__ double lane_get(double v, int srclane) {
+    if (UNIFORM) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+        return __hiloint2double(hi, lo);
+    }
+    return __shfl(v, srclane);
+}
+
 // Gaussian elimination with partial pivoting of an 8x8 system, one augmented row (9 doubles) per
 // lane: lanes base..base+7 of the wave hold rows 0..7.  Same operation order as solve_aug() in the
 // oracle.  Returns the solution component of this lane's row; ok is group-uniform.
+// UNIFORM = the wave holds a single system (base is wave-uniform).
+template <bool UNIFORM>
 __device__ double ge_solve8(double (&M)[9], int row, int base, bool &ok) {
     ok = true;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         int piv = c;
-        double best = fabs(__shfl(M[c], base + c));
+        double best = fabs(lane_get<UNIFORM>(M[c], base + c));
 #pragma unroll
         for (int r = c + 1; r < 8; ++r) {
-            const double v = fabs(__shfl(M[c], base + r));
+            const double v = fabs(lane_get<UNIFORM>(M[c], base + r));
             if (v > best) { best = v; piv = r; }
         }
         if (!(best > 1e-300)) ok = false;
-        // swap rows c and piv (every lane takes part in the shuffles)
+        if (UNIFORM) piv = __builtin_amdgcn_readfirstlane(piv);
+        // swap rows c and piv (every lane takes part in the exchange)
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const double from_piv = __shfl(M[k], base + piv), from_c = __shfl(M[k], base + c);
+            const double from_piv = lane_get<UNIFORM>(M[k], base + piv), from_c = lane_get<UNIFORM>(M[k], base + c);
             M[k] = (row == c) ? from_piv : ((row == piv) ? from_c : M[k]);
         }
-        const double inv = 1.0 / __shfl(M[c], base + c);
+        const double inv = 1.0 / lane_get<UNIFORM>(M[c], base + c);
         const double f = M[c] * inv;
 #pragma unroll
         for (int k = c; k < 9; ++k) {
-            const double prow = __shfl(M[k], base + c);
+            const double prow = lane_get<UNIFORM>(M[k], base + c);
             if (row > c) M[k] = M[k] - f * prow;
         }
     }
@@ -90,7 +105,7 @@ __device__ double ge_solve8(double (&M)[9], int row, int base, bool &ok) {
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
         // lane k finalises x_k = s / M[k][k]; every row above it (row < k) eliminates it
-        const double xk = __shfl(s / M[k], base + k);
+        const double xk = lane_get<UNIFORM>(s / M[k], base + k);
         if (row == k) x = xk;
         if (row < k) s = s - M[k] * xk;
     }
@@ -99,9 +114,9 @@ __device__ double ge_solve8(double (&M)[9], int row, int base, bool &ok) {
 
 __device__ __forceinline__ double reproj_err2(const double (&H)[9], const float4 p) {
     const double x = p.x, y = p.y, u = p.z, v = p.w;
-    const double w = H[6] * x + H[7] * y + H[8];
-    const double dx = (H[0] * x + H[1] * y + H[2]) / w - u;
-    const double dy = (H[3] * x + H[4] * y + H[5]) / w - v;
+    const double rw = 1.0 / (H[6] * x + H[7] * y + H[8]);  // one division; same sequence as the oracle
+    const double dx = (H[0] * x + H[1] * y + H[2]) * rw - u;
+    const double dy = (H[3] * x + H[4] * y + H[5]) * rw - v;
     return dx * dx + dy * dy;
 }
 
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(256) void hyp_kernel(const float *__restrict__ pts,
         M[4] = (row == 4); M[5] = (row == 5); M[6] = (row == 6); M[7] = (row == 7);
     }
     bool ok;
-    double h = ge_solve8(M, row, base, ok);
+    double h = ge_solve8<false>(M, row, base, ok);
     good = good && ok;
     // every component must be finite
     const bool fin = isfinite(h);
@@ -165,10 +180,11 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ pt
 }
 
 // ---- kernel 3: per-pair finish ------------------------------------------------------------------
-constexpr int kFinThreads = 1024;
+constexpr int kFinThreads = 512;
 constexpr int kFinWaves = kFinThreads / 64;
 
 struct FinShared {
+    double rows[kFinWaves][64][18];  // per wave: the two 9-element rows of 64 correspondences
     double gram[kFinWaves][81];
     double red[kFinWaves][12];
     double G[81];       // reduced gram
@@ -207,19 +223,32 @@ __device__ void block_sum(FinShared &sh, const double (&v)[K], double *dst) {
     __syncthreads();
 }
 
-// Accumulate sum over this wave's rows of r r^T (r in R^9) on the f64 matrix core.
-// gen(n, rt, i) returns element i of row type rt (0 = x-row, 1 = y-row) of correspondence n
-// (already multiplied by its weight^(1/2) / mask); n >= N must return 0.
+// Accumulate sum over all correspondences of (rx rx^T + ry ry^T), rx, ry in R^9, on the f64 matrix
+// core.  gen(n, rx, ry) fills the two rows of correspondence n (weight / mask already applied).
+// Each lane generates the rows of ONE correspondence per step (64 per wave) and parks them in the
+// wave's LDS slab; the MFMA operand of lane (i = lane&15, k = lane>>4) is then one LDS read:
+// element i of row (k&1) of correspondence 2j + (k>>1) -- the same value serves as A and as B.
 template <class Gen>
 __device__ void gram_accumulate(FinShared &sh, int N, Gen gen, double *dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, k = lane >> 4;
     f64x4 acc = {0, 0, 0, 0};
-    // each MFMA consumes 2 correspondences (4 rows); waves interleave pairs of correspondences
-    for (int n0 = wave * 2; n0 < N; n0 += kFinWaves * 2) {
-        const int n = n0 + (k >> 1);
-        const double e = (i < 9 && n < N) ? gen(n, k & 1, i) : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e, e, acc, 0, 0, 0);
+    double(*rows)[18] = sh.rows[wave];
+    for (int base = wave * 64; base < N; base += kFinWaves * 64) {
+        const int n = base + lane;
+        double rx[9], ry[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { rx[q] = 0.0; ry[q] = 0.0; }
+        if (n < N) gen(n, rx, ry);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { rows[lane][q] = rx[q]; rows[lane][9 + q] = ry[q]; }
+        __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; this only pins the compiler
+        const int cnt = min(64, N - base);
+        for (int j = 0; 2 * j < cnt; ++j) {
+            const double e = (i < 9) ? rows[2 * j + (k >> 1)][(k & 1) * 9 + i] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e, e, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     // D[row][col]: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
@@ -236,7 +265,7 @@ __device__ void gram_accumulate(FinShared &sh, int N, Gen gen, double *dst) {
     __syncthreads();
 }
 
-__device__ __forceinline__ double rl(double v, int srclane) { return __shfl(v, srclane); }
+__device__ __forceinline__ double rl(double v, int srclane) { return lane_get<true>(v, srclane); }  // srclane is a compile-time constant at every call
 
 // cyclic Jacobi on wave 0: lane r (< 9) holds row r of A and of V.  Same rotation order and
 // formulas as jacobi_eig() in the oracle.  On return lane r holds A[r][*] (diag = eigenvalues)
@@ -406,15 +435,12 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
     dlt_ok = dlt_ok && sh.stats[5] > 1e-300 && sh.stats[6] > 1e-300 && sh.stats[7] > 1e-300 && sh.stats[8] > 1e-300;
     const double sx = sw / sh.stats[5], sy = sw / sh.stats[6], su = sw / sh.stats[7], sv = sw / sh.stats[8];
     if (dlt_ok) {
-        gram_accumulate(sh, N, [&](int n, int rt, int i) -> double {
-            const double w = point_w(n, Hb);
+        gram_accumulate(sh, N, [&](int n, double (&rx)[9], double (&ry)[9]) {
+            const double sw_ = sqrt(point_w(n, Hb));
             const float4 p = pts[n];
-            const double X = (p.x - cx) * sx, Y = (p.y - cy) * sy, x = (p.z - cu) * su, y = (p.w - cv) * sv;
-            const int g = i / 3, j = i - 3 * g;
-            const double tri = (j == 0) ? X : (j == 1 ? Y : 1.0);
-            const double q = rt ? y : x;
-            const double val = (g == 2) ? -q * tri : ((g == rt) ? tri : 0.0);
-            return sqrt(w) * val;
+            const double X = (p.x - cx) * sx * sw_, Y = (p.y - cy) * sy * sw_, x = (p.z - cu) * su, y = (p.w - cv) * sv;
+            rx[0] = X; rx[1] = Y; rx[2] = sw_; rx[6] = -x * X; rx[7] = -x * Y; rx[8] = -x * sw_;
+            ry[3] = X; ry[4] = Y; ry[5] = sw_; ry[6] = -y * X; ry[7] = -y * Y; ry[8] = -y * sw_;
         }, sh.G);
         // eigenvector of the smallest eigenvalue (wave 0, one matrix row per lane)
         if (wave == 0) {
@@ -476,20 +502,15 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
         double h[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = hsrc[k];
-        gram_accumulate(sh, N, [&](int n, int rt, int i) -> double {
-            const double w = point_w(n, Hb);
+        gram_accumulate(sh, N, [&](int n, double (&rx)[9], double (&ry)[9]) {
+            const double w = point_w(n, Hb);  // 0/1 here
             const float4 p = pts[n];
             const double X = p.x, Y = p.y, u = p.z, v = p.w;
-            const double ww = 1.0 / (h[6] * X + h[7] * Y + 1.0);
+            const double ww = w != 0.0 ? 1.0 / (h[6] * X + h[7] * Y + 1.0) : 0.0;  // masked points contribute exact zeros
             const double xi = (h[0] * X + h[1] * Y + h[2]) * ww, yi = (h[3] * X + h[4] * Y + h[5]) * ww;
-            const double pi = rt ? yi : xi, ti = rt ? v : u;
-            const int g = i / 3, j = i - 3 * g;
-            const double tri = ((j == 0) ? X : (j == 1 ? Y : 1.0)) * ww;
-            double val;
-            if (i == 8) val = pi - ti;
-            else if (g == 2) val = -tri * pi;
-            else val = (g == rt) ? tri : 0.0;
-            return w * val;  // w is 0/1 here
+            // xi, yi carry the weight; for w = 1 these are the reference's Jacobian rows and residuals
+            rx[0] = X * ww; rx[1] = Y * ww; rx[2] = ww; rx[6] = -X * ww * xi; rx[7] = -Y * ww * xi; rx[8] = xi - w * u;
+            ry[3] = X * ww; ry[4] = Y * ww; ry[5] = ww; ry[6] = -X * ww * yi; ry[7] = -Y * ww * yi; ry[8] = yi - w * v;
         }, dst);
     };
     if (tid < 9) sh.h[tid] = sh.H[tid] / sh.H[8];
@@ -505,7 +526,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
             for (int j = 0; j < 8; ++j) M[j] = sh.G[row * 9 + j] + ((j == row) ? lambda * sh.G[row * 9 + row] : 0.0);
             M[8] = -sh.G[row * 9 + 8];
             bool ok;
-            const double d = ge_solve8(M, row, lane & ~7, ok);
+            const double d = ge_solve8<true>(M, row, 0, ok);
             if (lane < 8) sh.hn[lane] = sh.h[lane] + d;
             if (lane == 0) sh.hn[8] = 1.0;
             // step / parameter norms for the stopping rule

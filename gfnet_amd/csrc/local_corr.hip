@@ -51,6 +51,8 @@ constexpr int kFar = 1 << 28;             // patch origin of a cell that samples
 struct LcParams {
     const float *f0;
     const float *f1;
+    const float *f1_second;  // symmetric batches: f1 of directions b >= Bh (NULL: f1 holds all B maps)
+    int Bh;
     const float *flow;
     float *out;
     long f0_bs, out_bs;
@@ -71,6 +73,13 @@ struct LcParams {
 #else
 #define ABL(p, bit) false
 #endif
+
+// f1 map of direction b.  Symmetric batches are virtual: the second half of the directions reads
+// the other image's features (f1_second) instead of a concatenated copy (model/network.py:213-222).
+__device__ __forceinline__ const float *f1_of(const LcParams &p, int b) {
+    const size_t chw = (size_t)p.C * p.H * p.W;
+    return (b < p.Bh) ? p.f1 + (size_t)b * chw : p.f1_second + (size_t)(b - p.Bh) * chw;
+}
 
 struct Region {
     int x0, y0, w, h, pitch;
@@ -112,7 +121,7 @@ __device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, in
     const bool xa = (unsigned)x0 < (unsigned)p.W, xb = (unsigned)(x0 + 1) < (unsigned)p.W;
     const bool ya = (unsigned)y0 < (unsigned)p.H, yb = (unsigned)(y0 + 1) < (unsigned)p.H;
     const float *f0p = p.f0 + (size_t)b * p.f0_bs + (size_t)i * p.G + j;
-    const float *f1p = p.f1 + (size_t)b * p.C * p.H * p.W;
+    const float *f1p = f1_of(p, b);
     const size_t plane = (size_t)p.H * p.W, cs = (size_t)p.G * p.G;
     const long o00 = (long)y0 * p.W + x0;
     float acc = 0.f;
@@ -368,7 +377,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
 
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
-    const float *f1b = p.f1 + (size_t)b * p.C * H * W;
+    const float *f1b = f1_of(p, b);
     constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
     StageRegs<PRE> pre;
     if (STAGED && !ABL(p, 1)) {
@@ -583,11 +592,12 @@ GFN_EXPORT int64_t gfn_local_corr_scratch_bytes(int B, int G) {
     return 4 * ((int64_t)B * tiles + 1);
 }
 
-GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
-                                     int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based,
-                                     int win_h, int win_w, int variant, void *scratch, int64_t scratch_bytes,
-                                     gfn_stream_t stream) {
+GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second,
+                                     const float *flow, float *out, int64_t out_bs, int B, int C, int G, int H, int W,
+                                     int r, int grid_based, int win_h, int win_w, int variant, void *scratch,
+                                     int64_t scratch_bytes, gfn_stream_t stream) {
     if (!f0 || !f1 || !out) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: null tensor pointer");
+    if (f1_second && (B & 1)) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: symmetric batch must be even");
     if (B < 0 || C <= 0 || G <= 0 || H <= 0 || W <= 0 || r < 0 || win_h <= 0 || win_w <= 0)
         return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: bad size B=%d C=%d G=%d H=%d W=%d r=%d", B, C, G, H, W, r);
     const long K = (long)(2 * r + 1) * (2 * r + 1);
@@ -602,6 +612,8 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     hipStream_t s = (hipStream_t)stream;
     LcParams p;
     p.f0 = f0; p.f1 = f1; p.flow = flow; p.out = out;
+    p.f1_second = f1_second;
+    p.Bh = f1_second ? B / 2 : B;
     p.f0_bs = f0_bs; p.out_bs = out_bs;
     p.B = B; p.C = C; p.G = G; p.H = H; p.W = W;
     p.tiles_x = p.tiles_y = 0;
@@ -636,11 +648,12 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     return gfn::check_launch("local_corr_general_kernel");
 }
 
-GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
-                                  int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
-                                  int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream) {
-    return gfn_local_corr_fwd_ex(f0, f0_bs, f1, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0, scratch,
-                                 scratch_bytes, stream);
+GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second,
+                                  const float *flow, float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r,
+                                  int grid_based, int win_h, int win_w, void *scratch, int64_t scratch_bytes,
+                                  gfn_stream_t stream) {
+    return gfn_local_corr_fwd_ex(f0, f0_bs, f1, f1_second, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0,
+                                 scratch, scratch_bytes, stream);
 }
 
 namespace {

@@ -150,9 +150,8 @@ class GFNet(nn.Module):
         """GFNet.forward after feature extraction.  features*: dict scale -> (B,c,h,w), coarse to
         fine, keys "16".."1" (or "8".."1" when upsample).  image_hw: (H0, W0) of the network input."""
         H0, W0 = image_hw
-        if symmetric:  # network.py:213-222
-            features0, features1 = ({s: torch.cat((features0[s], features1[s])) for s in features0},
-                                    {s: torch.cat((features1[s], features0[s])) for s in features0})
+        # symmetric (network.py:213-222): the reference concatenates (A,B) and (B,A) pyramids; here the
+        # kernels index the two directions virtually, nothing is copied
         if upsample:
             num_grid, _, num_itr = self.num_grid_up, self.radius_up, self.num_itr_up
         else:
@@ -169,7 +168,7 @@ class GFNet(nn.Module):
                     flow = ops.interpolate_bilinear(pre_corresps["flow"], num_grid[0])          # :238-243
                     certainty = ops.interpolate_bilinear(pre_corresps["certainty"], num_grid[0])  # :244-249
                 else:
-                    flow = ops.corr_softargmax(f0, f1)                                           # :251-252
+                    flow = ops.corr_softargmax(f0, f1, symmetric=symmetric)                      # :251-252
                     certainty = torch.zeros((flow.shape[0], 1) + tuple(flow.shape[2:]), device=flow.device)  # :253
             corresps[scale] = {}
             disp_prev = torch.empty_like(flow)

@@ -32,18 +32,21 @@ def _timed(name, launch):
     return r
 
 
-def corr_softargmax(feat0, feat1):
+def corr_softargmax(feat0, feat1, symmetric=False):
     """pos_embed(corr_volume(feat0, feat1)) without writing the volume (model/network.py:251-252, 415-440).
-    feat0 (B,C,H0,W0), feat1 (B,C,H1,W1) -> flow (B,2,H0,W0)."""
+    feat0 (B,C,H0,W0), feat1 (B,C,H1,W1) -> flow (B,2,H0,W0).  symmetric=True: the result has 2B
+    directions, (feat0 vs feat1) then (feat1 vs feat0) -- the reference's concatenated batch
+    (network.py:213-222) without copying the features."""
     dev = require_gpu(feat0, feat1)
     f0, f1 = f32c(feat0), f32c(feat1)
     B, C, H0, W0 = f0.shape
     B1, C1, H1, W1 = f1.shape
     if B1 != B or C1 != C:
         raise ValueError("feat0/feat1 batch or channel mismatch")
-    flow = torch.empty((B, 2, H0, W0), device=dev, dtype=torch.float32)
-    check(_L().gfn_corr_softargmax_fwd(ptr(f0), ptr(f1), ptr(flow), B, C, H0, W0, H1, W1, stream_ptr(dev)),
-          "gfn_corr_softargmax_fwd")
+    nb = 2 * B if symmetric else B
+    flow = torch.empty((nb, 2, H0, W0), device=dev, dtype=torch.float32)
+    check(_L().gfn_corr_softargmax_fwd(ptr(f0), ptr(f1), ptr(flow), nb, C, H0, W0, H1, W1, 1 if symmetric else 0,
+                                       stream_ptr(dev)), "gfn_corr_softargmax_fwd")
     return flow
 
 
@@ -73,13 +76,16 @@ def pos_embed(corr_vol):
 def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_factor=1.0, corr_in_other=True):
     """The concat tensor `d` of ConvRefiner.forward (model/network.py:533-558):
     cat(grid_sample(x, cell centres), grid_sample(y, flow), disp_emb(40/32*scale_factor*(flow-centres)),
-    local_correlation(...)) -- every slice written in place by the HIP kernels, no torch.cat."""
+    local_correlation(...)) -- every slice written in place by the HIP kernels, no torch.cat.
+    If flow has twice the batch of x/y the call is symmetric: directions (x vs y) then (y vs x)."""
     dev = require_gpu(x, y, flow, disp_w, disp_b)
     x, y, fl = f32c(x), f32c(y), f32c(flow)
-    B, C, Hs, Ws = x.shape
+    Bi, C, Hs, Ws = x.shape
     G = int(num_grid)
-    if tuple(y.shape) != (B, C, Hs, Ws) or tuple(fl.shape) != (B, 2, G, G):
-        raise ValueError(f"refiner_input: y must be {(B, C, Hs, Ws)} and flow {(B, 2, G, G)}, got {tuple(y.shape)}, {tuple(fl.shape)}")
+    B = fl.shape[0]
+    symmetric = B == 2 * Bi
+    if tuple(y.shape) != (Bi, C, Hs, Ws) or tuple(fl.shape[1:]) != (2, G, G) or B not in (Bi, 2 * Bi):
+        raise ValueError(f"refiner_input: y must be {(Bi, C, Hs, Ws)} and flow (B or 2B,2,{G},{G}), got {tuple(y.shape)}, {tuple(fl.shape)}")
     w = f32c(disp_w).reshape(-1, 2)
     bvec = f32c(disp_b).reshape(-1)
     Dd = w.shape[0]
@@ -89,15 +95,15 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
     st = stream_ptr(dev)
     check(_L().gfn_refiner_input_fwd(ptr(x), ptr(y), ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
-                                     float(40 / 32 * scale_factor), st), "gfn_refiner_input_fwd")
+                                     float(40 / 32 * scale_factor), 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
     if corr_in_other:
         out = d[:, 2 * C + Dd:]
         nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
         scr = _lib.scratch(dev, nscr)
         check(_timed(f"local_corr_c{C}_h{Hs}_g{G}_r{r}",
-                     lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(fl), c_vp(out.data_ptr()), CH * G * G,
-                                                     B, C, G, Hs, Ws, r, 0, Hs, Ws, ptr(scr), nscr, st)),
-              "gfn_local_corr_fwd")
+                     lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, ptr(fl),
+                                                     c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws,
+                                                     ptr(scr), nscr, st)), "gfn_local_corr_fwd")
     return d
 
 

@@ -67,7 +67,7 @@ def local_correlation(featuremap_size, feature0, feature1, local_radius, num_gri
     hh, ww = h, w
     for level in range(int(num_level)):
         o = res[:, level * K1:(level + 1) * K1]
-        _lib.check(L.gfn_local_corr_fwd_ex(_lib.ptr(f0), f0_bs, _lib.ptr(f1), _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
+        _lib.check(L.gfn_local_corr_fwd_ex(_lib.ptr(f0), f0_bs, _lib.ptr(f1), None, _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
                                            out_bs, B, c, G, hh, ww, r, 1 if grid_based_correlation else 0, h, w,
                                            int(_variant), _lib.ptr(scr), nscr, st), "gfn_local_corr_fwd")
         if level + 1 < num_level:

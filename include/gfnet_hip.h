@@ -55,7 +55,10 @@ int gfn_device_arch(char *buf, int buflen);
  * (local_correlation.py:61-71) the caller passes the pooled f1 with the original win_h/win_w.
  *
  *   f0   (B,C,G,G)  batch stride f0_bs floats (>= C*G*G; lets f0 live inside a concat buffer)
- *   f1   (B,C,H,W)  contiguous
+ *   f1   (B,C,H,W)  contiguous; or, for a symmetric batch (model/network.py:213-222 concatenates
+ *                   (A,B) against (B,A)), f1 = the B-image maps (B/2,C,H,W) used by directions
+ *                   b < B/2 and f1_second = the A-image maps used by b >= B/2 -- no concatenated
+ *                   copy is needed.  f1_second == NULL: plain batch.
  *   flow (B,2,G,G)  contiguous, or NULL
  *   out  (B,K,G,G)  batch stride out_bs floats (>= K*G*G), K = (2r+1)^2
  *
@@ -66,14 +69,14 @@ int gfn_device_arch(char *buf, int buflen);
  * the general per-tap kernel.  Flow values are unrestricted (out-of-image taps read zeros).
  */
 int64_t gfn_local_corr_scratch_bytes(int B, int G);
-int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out, int64_t out_bs,
-                       int B, int C, int G, int H, int W, int r, int grid_based, int win_h, int win_w, void *scratch,
-                       int64_t scratch_bytes, gfn_stream_t stream);
+int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second, const float *flow,
+                       float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
+                       int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
 /* Variant selector for experiments/tests: 0 = auto (as above), 1 = force the general per-tap
  * kernel.  Same arguments otherwise. */
-int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *flow, float *out,
-                          int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
+int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second, const float *flow,
+                          float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                           int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
 /* F.avg_pool2d(x, 2, 2) between correlation levels (utils/local_correlation.py:71).
@@ -85,13 +88,15 @@ int gfn_avg_pool2(const float *in, float *out, int BC, int H, int W, gfn_stream_
  * (GFNet.pos_embed), called at :251-252.
  *   V[b,j,i]     = sum_c f0[b,c,i] * f1[b,c,j] / sqrt(C)        vol: (B,H1,W1,H0,W0)
  *   flow[b,:,i]  = sum_j softmax_j(V[b,j,i]) * (x_j, y_j)        flow: (B,2,H0,W0)
- * gfn_corr_softargmax_fwd is the fused form (the volume is never written);
+ * gfn_corr_softargmax_fwd is the fused form (the volume is never written); with symmetric != 0
+ * f0/f1 hold B/2 images each and directions b >= B/2 swap their roles (the reference's
+ * cat((A,B)) vs cat((B,A)) batch, model/network.py:213-222, without the copies);
  * gfn_corr_volume_fwd writes the volume (and the flow too when flow_or_null != NULL);
  * gfn_pos_embed_fwd is pos_embed on a caller-supplied volume.  f0 (B,C,H0,W0), f1 (B,C,H1,W1),
  * C <= 128.
  */
 int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B, int C, int H0, int W0, int H1, int W1,
-                            gfn_stream_t stream);
+                            int symmetric, gfn_stream_t stream);
 int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C, int H0, int W0,
                         int H1, int W1, gfn_stream_t stream);
 int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1, gfn_stream_t stream);
@@ -105,10 +110,12 @@ int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int 
  *                        disp_scale = 40/32 * scale_factor, disp_w (disp_dim,2), disp_b (disp_dim)
  * The local-correlation slice d[:, 2C+disp:] is filled by gfn_local_corr_fwd with
  * f0 = d (batch stride d_bs) and out = d + (2C+disp)*G*G (batch stride d_bs).
+ * symmetric != 0: f0/f1 hold B/2 images each; direction b < B/2 queries f0[b] against f1[b],
+ * direction b >= B/2 queries f1[b-B/2] against f0[b-B/2].
  */
 int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w, const float *disp_b,
                           float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
-                          gfn_stream_t stream);
+                          int symmetric, gfn_stream_t stream);
 
 /* F.grid_sample(in, grid, mode='bilinear', padding_mode='zeros', align_corners=False):
  * in (B,C,H,W), grid (B,Ho,Wo,2) -> out (B,C,Ho,Wo) with batch stride out_bs. */

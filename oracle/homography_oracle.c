@@ -103,9 +103,9 @@ static int solve4(const float *pts, const uint32_t idx[4], double H[9]) {
 /* squared reprojection error of one correspondence (OpenCV HomographyEstimatorCallback::computeError) */
 static inline double reproj_err2(const double H[9], const float *p) {
     const double x = p[0], y = p[1], u = p[2], v = p[3];
-    const double w = H[6] * x + H[7] * y + H[8];
-    const double dx = (H[0] * x + H[1] * y + H[2]) / w - u;
-    const double dy = (H[3] * x + H[4] * y + H[5]) / w - v;
+    const double rw = 1.0 / (H[6] * x + H[7] * y + H[8]); /* one division, like the GPU kernel (bit-identical inlier tests) */
+    const double dx = (H[0] * x + H[1] * y + H[2]) * rw - u;
+    const double dy = (H[3] * x + H[4] * y + H[5]) * rw - v;
     return dx * dx + dy * dy;
 }
 

@@ -30,7 +30,7 @@ def test_argument_errors_return_codes_without_a_gpu():
 
     L = _lib.lib()
     # null pointers / bad sizes are rejected before anything touches the device
-    assert L.gfn_local_corr_fwd(None, 0, None, None, None, 0, 1, 16, 4, 8, 8, 2, 0, 8, 8, None, 0, None) == -1
+    assert L.gfn_local_corr_fwd(None, 0, None, None, None, None, 0, 1, 16, 4, 8, 8, 2, 0, 8, 8, None, 0, None) == -1
     assert b"null" in L.gfn_last_error()
     assert L.gfn_interp_bilinear_fwd(None, None, 1, 2, 2, 2, 2, None) == -1
     assert L.gfn_kde_msplit(1, 20000, 20000) >= 1

@@ -244,3 +244,24 @@ def test_weighted_grid_dlt_matches_oracle():
     H1, _ = ops.homography_dlt(dev(pts), None)
     Ho1, _ = oracle.homography_dlt(pts)
     assert _ace(Ho1[0], host(H1)[0]) < 1e-3
+
+
+# ---- symmetric batches without the reference's concatenated pyramid copies (network.py:213-222) ----
+def test_symmetric_virtual_batch_equals_concatenated_batch():
+    from gfnet_amd import ops
+
+    B, c, hs, G, r, Dd = 2, 32, 56, 32, 4, 8
+    a = synth.lattice_normalish((B, c, hs, hs), 111)
+    b = synth.lattice_normalish((B, c, hs, hs), 112)
+    flow = np.concatenate((synth.homography_flow(B, G, 113), synth.homography_flow(B, G, 114, scale=0.95)))
+    w = synth.lattice_uniform((Dd, 2, 1, 1), 115)
+    bias = synth.lattice_uniform((Dd,), 116)
+    d_sym = ops.refiner_input(G, dev(a), dev(b), dev(flow), dev(w), dev(bias), r)
+    d_cat = ops.refiner_input(G, dev(np.concatenate((a, b))), dev(np.concatenate((b, a))), dev(flow), dev(w), dev(bias), r)
+    np.testing.assert_array_equal(host(d_sym), host(d_cat))
+    assert_close(host(d_sym), oracle.refiner_input(G, np.concatenate((a, b)), np.concatenate((b, a)), flow, w, bias, r), TOL, "d")
+    a16 = 2 * synth.lattice_normalish((B, 64, 16, 16), 117)
+    b16 = 2 * synth.lattice_normalish((B, 64, 16, 16), 118)
+    f_sym = ops.corr_softargmax(dev(a16), dev(b16), symmetric=True)
+    f_cat = ops.corr_softargmax(dev(np.concatenate((a16, b16))), dev(np.concatenate((b16, a16))))
+    np.testing.assert_array_equal(host(f_sym), host(f_cat))
