@@ -58,7 +58,7 @@ struct LcParams {
     long f0_bs, out_bs;
     int B, C, G, H, W;
     int tiles_x, tiles_y;
-    float sqrt_c;
+    float sqrt_c, inv_sqrt_c;
     int r, win_h, win_w, grid_based;  // general path / flagged cells
     float win_xhi, win_yhi;           // tiled path: linspace end points 2r/W, 2r/H rounded to fp32
     int *todo;                        // [1 + B*tiles]: count, then ids of tiles left to the irregular launch
@@ -246,8 +246,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     int *cellSlow = reinterpret_cast<int *>(cellNy + NC);    // [NC] 1 = redo this cell with the per-tap routine
     int *bbox = cellSlow + NC;                                // x0,y0,x1,y1 of the tile's windows
     int *nSlow = bbox + 4;                                    // number of flagged cells in the tile
+    int *allInside = bbox + 5;                                // 1 = no window of the tile touches the image border
     float *tab = dbuf + NC * DS;                              // [NC][TS] per-tap fractions (aliases the stage)
-    constexpr int kCellBytes = (NC * 20 + 16 + 16 + 15) & ~15;
+    constexpr int kCellBytes = (NC * 20 + 32 + 15) & ~15;
     float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);  // [NC][C+4]: the tile's f0, cell-major
     const int CS = p.C + 4;                                   // +4: the 4 cells a wave reads hit different banks
 
@@ -260,7 +261,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
 
     // ---- per-cell setup: patch origin, bounding box -------------------------------------------
     if (tid < 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
-    if (tid == 0) *nSlow = 0;
+    if (tid == 0) { *nSlow = 0; *allInside = 1; }
     __syncthreads();
     const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;  // +-2r/W, +-2r/H as fp32
     // the tile's f0 block (NC cells x C channels, 8-16 KB): coalesced 64-byte row segments -> LDS,
@@ -289,6 +290,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
         }
     }
     int bx0 = kFar, by0 = kFar, bx1 = -kFar, by1 = -kFar;  // this cell's window clipped to the image
+    bool inside = true;                                      // ... and whether clipping changed nothing
     if (tid < NC) {
         const int ci = tid >> 4, cj = tid & 15;
         const int gi = ty * TH + ci, gj = tx * kTileW + cj;
@@ -306,10 +308,12 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
                 if (STAGED) {
                     const int x0 = max(X0, 0), x1 = min(X0 + PW, W), y0 = max(Y0, 0), y1 = min(Y0 + PW, H);
                     if (x0 < x1 && y0 < y1) { bx0 = x0; by0 = y0; bx1 = x1; by1 = y1; }
+                    inside = (X0 >= 0) & (X0 + PW <= W) & (Y0 >= 0) & (Y0 + PW <= H);
                 }
             } else {
                 slow = 1;  // non-finite / absurd flow: let the per-tap routine decide
                 atomicAdd(nSlow, 1);
+                inside = false;
             }
         }
         cellX0[tid] = X0;
@@ -325,11 +329,14 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
             bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
             bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
         }
+        // cells off the grid or with absurd flow have inside == true but an empty box: harmless
+        const bool all_in = __all(inside || tid >= NC);
         if (lane == 0) {
             atomicMin(bbox + 0, bx0);
             atomicMin(bbox + 1, by0);
             atomicMax(bbox + 2, bx1);
             atomicMax(bbox + 3, by1);
+            if (!all_in) *allInside = 0;
         }
     }
     // the zero slot (index kCapSlots) is what every out-of-image tap reads
@@ -351,21 +358,29 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     int g, s16;
     lane_group(lane, g, s16);
     const int cr = wave * 4 + g;  // cell inside a round (0..31): row cr>>4, column cr&15
+    const bool interior = STAGED && *allInside != 0;  // block-uniform
     unsigned apk[ROUNDS][(NP + 1) / 2];  // staged: float4 index (< 2^16) of each (round, pass) patch pixel, two per register
     float acc[ROUNDS][NP];
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
         const int X0 = cellX0[cell], Y0 = cellY0[cell];
+        // interior tiles (no window touches the border, every cell on the grid): no per-pixel tests
+        const int base = (Y0 - u.y0) * u.pitch + (X0 - u.x0);
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
             acc[rd][t] = 0.f;
             if (STAGED) {
                 const int pp = s16 + 16 * t;
                 const int yy = pp / PW, xx = pp - yy * PW;
-                const int X = X0 + xx, Y = Y0 + yy;
-                const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
-                const int slot = in ? (Y - u.y0) * u.pitch + (X - u.x0) : kCapSlots;
+                int slot;
+                if (interior) {
+                    slot = (pp < P && X0 != kFar) ? base + yy * u.pitch + xx : kCapSlots;
+                } else {
+                    const int X = X0 + xx, Y = Y0 + yy;
+                    const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
+                    slot = in ? (Y - u.y0) * u.pitch + (X - u.x0) : kCapSlots;
+                }
                 const unsigned a = (unsigned)(slot * kSlotV4);
                 if (t & 1)
                     apk[rd][t >> 1] |= a << 16;
@@ -499,24 +514,35 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
         const int kphase = (wave % (kWaves / NCB)) * (64 / CW) + (lane / CW);
         const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
         if (gi < G && gj < G && !cellSlow[cell] && !ABL(p, 8)) {
+            // one tap ROW (ky) at a time: the two D rows it needs are read once (2*PW LDS reads for D
+            // outputs), the column fractions of the cell stay in registers
             const float *dc = dbuf + cell * DS;
             const float *tc = tab + cell * TS;
             float *o = p.out + (size_t)b * p.out_bs + (size_t)gi * G + gj;
-            constexpr int NK = (K + WPB - 1) / WPB;
-#pragma unroll 4
-            for (int n = 0; n < NK; ++n) {  // constant trip count: the LDS reads of several taps overlap
-                const int k = kphase + n * WPB;
-                if (k < K) {
-                    const int ky = k / D, kx = k - ky * D;
-                    const float wx1 = tc[kx], wy1 = tc[D + ky];
-                    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                    const float *d = dc + ky * PW + kx;
-                    // corner order and weights as grid_sample: nw, ne, sw, se
-                    float v = d[0] * (wx0 * wy0);
-                    v += d[1] * (wx1 * wy0);
-                    v += d[PW] * (wx0 * wy1);
-                    v += d[PW + 1] * (wx1 * wy1);
-                    o[(size_t)k * cs] = v / p.sqrt_c;
+            float wx1[D];
+#pragma unroll
+            for (int kx = 0; kx < D; ++kx) wx1[kx] = tc[kx];
+            constexpr int NR = (D + WPB - 1) / WPB;
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int ky = kphase + n * WPB;
+                if (ky < D) {
+                    const float wy1 = tc[D + ky], wy0 = 1.f - wy1;
+                    const float *d = dc + ky * PW;
+                    float top[PW], bot[PW];
+#pragma unroll
+                    for (int x = 0; x < PW; ++x) { top[x] = d[x]; bot[x] = d[PW + x]; }
+                    float *ok = o + (size_t)(ky * D) * cs;
+#pragma unroll
+                    for (int kx = 0; kx < D; ++kx) {
+                        const float wx0 = 1.f - wx1[kx];
+                        // corner order and weights as grid_sample: nw, ne, sw, se
+                        float v = top[kx] * (wx0 * wy0);
+                        v += top[kx + 1] * (wx1[kx] * wy0);
+                        v += bot[kx] * (wx0 * wy1);
+                        v += bot[kx + 1] * (wx1[kx] * wy1);
+                        ok[(size_t)kx * cs] = v * p.inv_sqrt_c;
+                    }
                 }
             }
         }
@@ -538,6 +564,16 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
 template <int R, int ROUNDS>
 __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef GFN_ABLATE
+    {   // experiment: de-synchronise the two workgroups of a CU (first dispatch wave only)
+        const unsigned bid = blockIdx.x;
+        const bool late = (ABL(p, 64) && ((bid >> 8) & 1)) || (ABL(p, 128) && (bid & 1)) || (ABL(p, 256) && ((bid >> 3) & 1));
+        if (late && bid < 512) {
+            const int n = p.dbg >> 12;  // sleep units of ~64*127 cycles
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
     process_tile<R, ROUNDS, true>(p, gfn::xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
@@ -561,7 +597,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     p.r = R; p.win_h = p.H; p.win_w = p.W; p.grid_based = 0;  // what tap_general needs for flagged cells
     p.win_xhi = (float)(2.0 * R / p.W);
     p.win_yhi = (float)(2.0 * R / p.H);
-    const size_t lds = kStageBytes + ((NC * 20 + 16 + 16 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
+    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
     // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
     // one workgroup per CU; absurdly wide features go to the general kernel
     if (lds > kMaxLds) return -1000;
@@ -618,6 +654,7 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     p.B = B; p.C = C; p.G = G; p.H = H; p.W = W;
     p.tiles_x = p.tiles_y = 0;
     p.sqrt_c = (float)sqrt((double)C);
+    p.inv_sqrt_c = (float)(1.0 / sqrt((double)C));
     p.r = r; p.win_h = win_h; p.win_w = win_w; p.grid_based = grid_based;
     p.todo = reinterpret_cast<int *>(scratch);
     p.todo_ints = scratch ? scratch_bytes / 4 : 0;
