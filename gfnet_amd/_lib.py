@@ -30,6 +30,8 @@ _SIGNATURES = {
     "gfn_match_post_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_int] * 4 + [c_vp],
     "gfn_kde_msplit": [c_int, c_int, c_int],
     "gfn_kde_density": [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64, c_i64, c_double, c_vp, c_i64, c_vp],
+    "gfn_kde_morton_keys": [c_vp, c_vp, c_i64, c_vp],
+    "gfn_kde_density_sorted": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_double, c_vp, c_i64, c_vp],
     "gfn_threshold_certainty": [c_vp, c_vp, c_i64, c_float, c_vp],
     "gfn_balance_weights": [c_vp, c_vp, c_i64, c_float, c_float, c_vp],
     "gfn_convert_matches": [c_vp, c_vp, c_i64] + [c_float] * 4 + [c_vp],
@@ -41,6 +43,7 @@ _SIGNATURES = {
 _SIZE_FUNCS = {
     "gfn_local_corr_scratch_bytes": [c_int, c_int],
     "gfn_kde_scratch_floats": [c_int, c_int, c_int, c_int],
+    "gfn_kde_sorted_scratch_floats": [c_int, c_int, c_int],
     "gfn_homography_scratch_bytes": [c_int, c_int],
 }
 

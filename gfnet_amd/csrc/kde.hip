@@ -72,6 +72,116 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_kernel(const float *__restri
     if (n < N) part[((size_t)bt * MS + ms) * N + n] = acc.x + acc.y;
 }
 
+// ---- spatially culled variant -------------------------------------------------------------------
+// With std = 0.1 on coordinates in [-1,1] a term is below 2^-32 once the points are 6.7 std apart,
+// and the matches lie on a 2-D manifold of the 4-D space, so most of the N x M pairs contribute
+// nothing.  The caller sorts queries and reference points along a Morton curve of the A-image
+// coordinates (gfn_kde_morton_keys + a sort); every 64 consecutive points then form a compact block.
+// Each wave owns one block of 64 queries, keeps its bounding box, and skips every reference block
+// whose box is farther than the cut-off (wave-uniform test on 8 scalars); the surviving blocks run
+// the same packed inner loop as kde4_kernel.  Truncation error < M * 2^-32 absolute (densities
+// are >= 1 from the self term).
+constexpr float kKdeCutoffLog2 = 32.f;
+
+__global__ __launch_bounds__(256) void kde4_morton_kernel(const float *__restrict__ x, int *__restrict__ keys, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    // 8 bits per axis of the A-image position (the B-image position follows it for inliers)
+    const unsigned qx = (unsigned)fminf(fmaxf((v.x + 1.f) * 128.f, 0.f), 255.f);
+    const unsigned qy = (unsigned)fminf(fmaxf((v.y + 1.f) * 128.f, 0.f), 255.f);
+    unsigned key = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) key |= (((qx >> b) & 1u) << (2 * b)) | (((qy >> b) & 1u) << (2 * b + 1));
+    keys[i] = (int)key;
+}
+
+// ys: pre-scaled point pairs (Bt, Mp/2, 4, 2) as written by kde4_prescale_kernel; box: (Bt, nblk, 8) =
+// min[4], max[4] of each block of 64 reference points (32 pairs).  One wave per block.
+__global__ __launch_bounds__(256) void kde4_bbox_kernel(const float *__restrict__ ys, float *__restrict__ box, int M, int Mp,
+                                                        int Bt) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = (Mp + 63) >> 6;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)Bt * nblk) return;
+    const int bt = (int)(wid / nblk), blk = (int)(wid - (long)bt * nblk);
+    const int m = blk * 64 + lane;
+    float lo[4], hi[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float v = (m < M) ? ys[((size_t)bt * (Mp >> 1) + (m >> 1)) * 8 + d * 2 + (m & 1)] : 0.f;
+        lo[d] = (m < M) ? v : 3e38f;
+        hi[d] = (m < M) ? v : -3e38f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+        }
+    }
+    if (lane < 4) box[wid * 8 + lane] = lo[lane];
+    else if (lane < 8) box[wid * 8 + lane] = hi[lane - 4];
+}
+
+__global__ __launch_bounds__(kKdeThreads) void kde4_culled_kernel(const float *__restrict__ xs, const float *__restrict__ ys,
+                                                                  const float *__restrict__ box, float *__restrict__ part,
+                                                                  int N, int Mp) {
+    const int bt = blockIdx.z;
+    const int n = blockIdx.x * kKdeThreads + threadIdx.x;
+    const int MS = gridDim.y, ms = blockIdx.y;
+    const int nblk = (Mp + 63) >> 6;
+    const int per = (nblk + MS - 1) / MS;
+    const int b0 = ms * per, b1 = min(nblk, b0 + per);
+    const float4 xv = (n < N) ? reinterpret_cast<const float4 *>(xs)[(size_t)bt * N + n] : make_float4(0, 0, 0, 0);
+    // bounding box of this wave's 64 queries (idle lanes repeat lane 0's neighbourhood via +-inf)
+    float qlo[4] = {xv.x, xv.y, xv.z, xv.w}, qhi[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (n >= N) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { qlo[d] = 3e38f; qhi[d] = -3e38f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            qlo[d] = fminf(qlo[d], __shfl_xor(qlo[d], o));
+            qhi[d] = fmaxf(qhi[d], __shfl_xor(qhi[d], o));
+        }
+    }
+    const f32x2 x0 = {xv.x, xv.x}, x1 = {xv.y, xv.y}, x2 = {xv.z, xv.z}, x3 = {xv.w, xv.w};
+    const f32x2 *yp = reinterpret_cast<const f32x2 *>(ys) + (size_t)bt * (Mp >> 1) * 4;
+    const float *bx = box + (size_t)bt * nblk * 8;
+    f32x2 acc = {0.f, 0.f};
+    for (int blk = b0; blk < b1; ++blk) {
+        // squared distance between the two boxes (pre-scaled units: the exponent itself)
+        float d2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float g = fmaxf(fmaxf(qlo[d] - bx[blk * 8 + 4 + d], bx[blk * 8 + d] - qhi[d]), 0.f);
+            d2 = fmaf(g, g, d2);
+        }
+        if (d2 > kKdeCutoffLog2) continue;  // the same for every lane of the wave
+        const int p0 = blk * 32, p1 = min(Mp >> 1, p0 + 32);
+#pragma unroll 4
+        for (int p = p0; p < p1; ++p) {
+            const f32x2 e0 = x0 - yp[(size_t)p * 4 + 0];
+            const f32x2 e1 = x1 - yp[(size_t)p * 4 + 1];
+            const f32x2 e2 = x2 - yp[(size_t)p * 4 + 2];
+            const f32x2 e3 = x3 - yp[(size_t)p * 4 + 3];
+            f32x2 sq = e0 * e0;
+            sq = __builtin_elementwise_fma(e1, e1, sq);
+            sq = __builtin_elementwise_fma(e2, e2, sq);
+            sq = __builtin_elementwise_fma(e3, e3, sq);
+            f32x2 e;
+            e.x = __builtin_amdgcn_exp2f(-sq.x);
+            e.y = __builtin_amdgcn_exp2f(-sq.y);
+            acc += e;
+        }
+    }
+    if (n < N) part[((size_t)bt * MS + ms) * N + n] = acc.x + acc.y;
+}
+
 // any point dimension D (the reference never uses anything but 4)
 __global__ __launch_bounds__(kKdeThreads) void kde_generic_kernel(const float *__restrict__ x,
                                                                   const float *__restrict__ y, float *__restrict__ part,
@@ -139,6 +249,54 @@ GFN_EXPORT int gfn_balance_weights(const float *density, float *p, int64_t n, fl
     hipLaunchKernelGGL(balance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, density, p,
                        (long)n, min_density, floor_p);
     return gfn::check_launch("balance_kernel");
+}
+
+GFN_EXPORT int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_stream_t stream) {
+    if (!x || !keys || n < 0 || ((uintptr_t)x & 15)) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_morton_keys: bad argument");
+    if (n == 0) return GFN_OK;
+    hipLaunchKernelGGL(kde4_morton_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, keys, (long)n);
+    return gfn::check_launch("kde4_morton_kernel");
+}
+
+// Scratch floats for gfn_kde_density_sorted: pre-scaled copies, block boxes, split-M partials.
+GFN_EXPORT int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M) {
+    const int Mp = (M + 1) & ~1;
+    return (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4 + (int64_t)Bt * ((Mp + 63) / 64) * 8 + (int64_t)Bt * 32 * N + 64;
+}
+
+// Density of spatially sorted 4-D points (see kde4_culled_kernel): x (Bt,N,4), y (Bt,M,4), both in
+// the order of their gfn_kde_morton_keys; out (Bt,N) in the order of x.
+GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, int N, int M, double std,
+                                      float *scratch, int64_t scratch_floats, gfn_stream_t stream) {
+    if (!x || !y || !out || !scratch) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_sorted: null pointer");
+    if (Bt < 0 || N < 0 || M <= 0 || !(std > 0) || Bt > 65535) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_sorted: bad argument");
+    if (scratch_floats < gfn_kde_sorted_scratch_floats(Bt, N, M) || ((uintptr_t)scratch & 15) || ((uintptr_t)x & 15))
+        return gfn::fail(GFN_ERR_SCRATCH, "kde_sorted: scratch too small or misaligned");
+    if (Bt == 0 || N == 0) return GFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = (float)sqrt(1.4426950408889634 / (2.0 * std * std));
+    const int Mp = (M + 1) & ~1, nblk = (Mp + 63) / 64;
+    float *xs = scratch, *ys = xs + (int64_t)Bt * N * 4, *box = ys + (int64_t)Bt * Mp * 4;
+    float *part = box + (((int64_t)Bt * nblk * 8 + 3) & ~3);
+    const long tot = (long)Bt * 4 * (N > Mp ? N : Mp);
+    hipLaunchKernelGGL(kde4_prescale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, y, xs, ys, N, M, 4L,
+                       (long)M * 4, scale, Bt);
+    hipLaunchKernelGGL(kde4_bbox_kernel, dim3((unsigned)(((long)Bt * nblk + 3) / 4)), dim3(256), 0, s, ys, box, M, Mp, Bt);
+    int MS = 1;
+    {   // same rule as the dense kernel: enough workgroups for the chip, at least 8 blocks of points per split
+        const long blocks = (long)Bt * ((N + kKdeThreads - 1) / kKdeThreads);
+        while (blocks * MS < 2048 && nblk / (MS * 2) >= 8 && MS < 32) MS *= 2;
+    }
+    float *dst = MS > 1 ? part : out;
+    hipLaunchKernelGGL(kde4_culled_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, ys, box,
+                       dst, N, Mp);
+    if (int e = gfn::check_launch("kde4_culled_kernel")) return e;
+    if (MS > 1) {
+        const long total = (long)Bt * N;
+        hipLaunchKernelGGL(kde_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, out, N, MS, Bt);
+        return gfn::check_launch("kde_reduce_kernel");
+    }
+    return GFN_OK;
 }
 
 GFN_EXPORT int gfn_kde_msplit(int Bt, int N, int M) {

@@ -166,8 +166,10 @@ def match_post(flow, certainty, cert16=None, symmetric=True):
     return warp, cout
 
 
-def kde_density(x, y=None, std=0.1, y_row_stride=None):
-    """sum_m exp(-|x_n - y_m|^2/(2 std^2)); x (N,D) or (Bt,N,D); y defaults to x.  fp32."""
+def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None):
+    """sum_m exp(-|x_n - y_m|^2/(2 std^2)); x (N,D) or (Bt,N,D); y defaults to x.  fp32.
+    cull (default: automatic for 4-D points, N >= 4096): sort the points along a Morton curve of the
+    A-image coordinates and skip blocks of reference points beyond 6.7 std (terms < 2^-32)."""
     dev = require_gpu(x, y)
     xs = f32c(x)
     squeeze = xs.dim() == 2
@@ -184,12 +186,44 @@ def kde_density(x, y=None, std=0.1, y_row_stride=None):
     if y_row_stride is not None:  # strided view of ys (x[::down]) without a copy
         rs = int(y_row_stride)
         M = (ys.shape[1] * D + rs - 1) // rs
+    if cull is None:
+        cull = D == 4 and N >= 4096 and M >= 4096 and std <= 0.2
+    if cull and D == 4:
+        if y_row_stride is not None:
+            ys = ys[:, ::rs // D].contiguous()
+        same = y is None and y_row_stride is None
+        out = _kde_culled(xs, xs if same else ys, std, same, dev)
+        return out[0] if squeeze else out
     out = torch.empty((Bt, N), device=dev, dtype=torch.float32)
     nscr = int(_L().gfn_kde_scratch_floats(Bt, N, M, D))
     scratch = torch.empty((max(nscr, 4),), device=dev, dtype=torch.float32)
     check(_L().gfn_kde_density(ptr(xs), ptr(ys), ptr(out), Bt, N, M, D, rs, bs, float(std), ptr(scratch), nscr,
                                stream_ptr(dev)), "gfn_kde_density")
     return out[0] if squeeze else out
+
+
+def _morton_sorted(pts, dev):
+    """(sorted points, permutation): rows ordered by the Morton key of their A-image position."""
+    Bt, N, _ = pts.shape
+    keys = torch.empty((Bt, N), device=dev, dtype=torch.int32)
+    check(_L().gfn_kde_morton_keys(ptr(pts), ptr(keys), Bt * N, stream_ptr(dev)), "gfn_kde_morton_keys")
+    perm = torch.argsort(keys, dim=1)
+    return torch.gather(pts, 1, perm[..., None].expand(Bt, N, 4)).contiguous(), perm
+
+
+def _kde_culled(xs, ys, std, same, dev):
+    Bt, N, _ = xs.shape
+    M = ys.shape[1]
+    xsort, perm = _morton_sorted(xs, dev)
+    ysort = xsort if same else _morton_sorted(ys, dev)[0]
+    dens = torch.empty((Bt, N), device=dev, dtype=torch.float32)
+    nscr = int(_L().gfn_kde_sorted_scratch_floats(Bt, N, M))
+    scratch = torch.empty((nscr,), device=dev, dtype=torch.float32)
+    check(_L().gfn_kde_density_sorted(ptr(xsort), ptr(ysort), ptr(dens), Bt, N, M, float(std), ptr(scratch), nscr,
+                                      stream_ptr(dev)), "gfn_kde_density_sorted")
+    out = torch.empty_like(dens)
+    out.scatter_(1, perm, dens)  # back to the caller's order
+    return out
 
 
 def threshold_certainty(certainty, thresh):

@@ -154,6 +154,15 @@ int64_t gfn_kde_scratch_floats(int Bt, int N, int M, int D);
 int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, int M, int D, int64_t y_row_stride,
                     int64_t y_batch_stride, double std, float *scratch, int64_t scratch_floats, gfn_stream_t stream);
 
+/* Spatially culled KDE for 4-D matches (same sum as gfn_kde_density up to terms below 2^-32): the
+ * caller orders x and y by gfn_kde_morton_keys (any stable sort of the int keys) and passes the
+ * sorted arrays; out is in the order of the sorted x.  scratch: gfn_kde_sorted_scratch_floats().
+ * Blocks of 64 reference points farther than 6.7 std from a wave's 64 queries are skipped. */
+int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_stream_t stream);
+int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M);
+int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, int N, int M, double std, float *scratch,
+                           int64_t scratch_floats, gfn_stream_t stream);
+
 /* GFNet.sample's elementwise steps (model/network.py:385-414):
  *   gfn_threshold_certainty: out = certainty > thresh ? 1 : certainty            (:391-393)
  *   gfn_balance_weights:     p = density < min_density ? floor_p : 1/(density+1)  (:409-410; 10, 1e-7)

@@ -265,3 +265,26 @@ def test_symmetric_virtual_batch_equals_concatenated_batch():
     f_sym = ops.corr_softargmax(dev(a16), dev(b16), symmetric=True)
     f_cat = ops.corr_softargmax(dev(np.concatenate((a16, b16))), dev(np.concatenate((b16, a16))))
     np.testing.assert_array_equal(host(f_sym), host(f_cat))
+
+
+def test_kde_culled_equals_dense_and_oracle_on_match_like_points():
+    """Spatially culled KDE (Morton-sorted blocks, 6.7-std cut-off) vs the dense kernel and the oracle on
+    points shaped like sampled warp rows: A positions over the image, B = homography(A) + noise, some outliers."""
+    from gfnet_amd import ops
+
+    rng = np.random.default_rng(7)
+    Bt, N = 2, 20000
+    a = rng.uniform(-1, 1, size=(Bt, N, 2))
+    b = np.stack([0.85 * a[..., 0] + 0.1 * a[..., 1] + 0.05, -0.08 * a[..., 0] + 0.9 * a[..., 1] - 0.03], -1)
+    b += 0.01 * rng.standard_normal(b.shape)
+    b[:, :2000] = rng.uniform(-1, 1, size=(Bt, 2000, 2))  # outliers
+    x = np.concatenate((a, b), -1).astype(np.float32)
+    dense = host(ops.kde_density(dev(x), std=0.1, cull=False))
+    culled = host(ops.kde_density(dev(x), std=0.1, cull=True))
+    np.testing.assert_allclose(culled, dense, rtol=2e-5)
+    for bt in range(Bt):
+        np.testing.assert_allclose(culled[bt], oracle.kde(x[bt], 0.1, half=False), rtol=1e-4)
+    # separate reference set (x[::8], the reference's CPU-branch subsampling)
+    y = np.ascontiguousarray(x[:, ::8])
+    c2 = host(ops.kde_density(dev(x), dev(y), std=0.1, cull=True))
+    np.testing.assert_allclose(c2[0], oracle.kde(x[0], 0.1, half=False, down=8), rtol=1e-4)
