@@ -225,8 +225,15 @@ __device__ __forceinline__ void stage_rest(float4 *s4, const float *f1c, int H, 
 //   STAGED = true : regular path -- the tile's windows are staged in LDS; a tile whose windows do
 //                   not fit is appended to p.todo and left to the second launch.
 //   STAGED = false: irregular path -- same arithmetic, patch pixels gathered straight from f1 (L2).
-template <int R, int ROUNDS, bool STAGED>
-__device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, unsigned char *smem) {
+// Geometry: the tile's NC = 32*ROUNDS cells form a block TW cells wide whose top-left cell is
+// (row0, col0) of image b's grid; only its first `rows` rows belong to it (sub-tiles of a 2-row tile).
+//   SECOND = false: first launch (TW = 16, one tile per workgroup).
+//   SECOND = true : second launch -- an irregular tile is cut into 4 x 8 sub-tiles, each staged on
+//                   its own (half the footprint along the grid row, so twice the magnification
+//                   fits); a sub-tile that still does not fit falls through to the gather variant.
+template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND>
+__device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0, int col0, int rows, unsigned wid,
+                                             unsigned char *smem) {
     constexpr int PW = 2 * R + 2;            // patch width: taps -R..R plus the +1 bilinear neighbour
     constexpr int P = PW * PW;               // patch positions per cell
     constexpr int NP = (P + 15) / 16;        // positions per lane
@@ -253,11 +260,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     const int CS = p.C + 4;                                   // +4: the 4 cells a wave reads hit different banks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles = p.tiles_x * p.tiles_y;
-    const int b = wid / tiles;
-    const int tile = wid - b * tiles;
-    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int G = p.G, H = p.H, W = p.W;
+    auto cell_gi = [&](int cell) { return row0 + cell / TW; };
+    auto cell_gj = [&](int cell) { return col0 + cell % TW; };
+    auto cell_ok = [&](int cell) { return (cell / TW < rows) & (row0 + cell / TW < G) & (col0 + cell % TW < G); };
 
     // ---- per-cell setup: patch origin, bounding box -------------------------------------------
     if (tid < 4) bbox[tid] = (tid & 2) ? -kFar : kFar;
@@ -276,8 +282,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
             for (int q = 0; q < UF; ++q) {
                 const int e = e0 + q * kThreads;
                 const int c = e / NC, cell = e - c * NC;
-                const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-                const bool ok = (e < total) & (gi < G) & (gj < G) & !ABL(p, 4);
+                const int gi = cell_gi(cell), gj = cell_gj(cell);
+                const bool ok = (e < total) & cell_ok(cell) & !ABL(p, 4);
                 v[q] = f0b[ok ? (size_t)c * G * G + (size_t)gi * G + gj : 0];  // clamped address, select below
                 v[q] = ok ? v[q] : 0.f;
             }
@@ -292,11 +298,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     int bx0 = kFar, by0 = kFar, bx1 = -kFar, by1 = -kFar;  // this cell's window clipped to the image
     bool inside = true;                                      // ... and whether clipping changed nothing
     if (tid < NC) {
-        const int ci = tid >> 4, cj = tid & 15;
-        const int gi = ty * TH + ci, gj = tx * kTileW + cj;
+        const int gi = cell_gi(tid), gj = cell_gj(tid);
         int X0 = kFar, Y0 = kFar, slow = 0;
         float nx = 0.f, ny = 0.f;
-        if (gi < G && gj < G) {
+        if (cell_ok(tid)) {
             cell_coords(p, b, gi, gj, nx, ny);
             // patch origin = floor of the reference's own fp32 coordinate of tap 0:
             // taps kx=0..2R then read columns kx and kx+1 of the patch
@@ -350,7 +355,12 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     u.pitch = u.w + ((PW - u.w) & 15);
     if (STAGED && (long)u.pitch * u.h > kCapSlots) {
         // strong magnification / rotation / scattered flow: the windows do not fit the stage
-        if (tid == 0) p.todo[1 + atomicAdd(p.todo, 1)] = (int)wid;
+        if (!SECOND) {
+            if (tid == 0) p.todo[1 + atomicAdd(p.todo, 1)] = (int)wid;
+        } else {
+            __syncthreads();
+            process_tile<R, ROUNDS, false, TW, true>(p, b, row0, col0, rows, wid, smem);  // gather from L2
+        }
         return;
     }
 
@@ -512,8 +522,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
         constexpr int WPB = kWaves / NCB * (64 / CW);   // tap phases sharing one group of cells
         const int cell = (wave / (kWaves / NCB)) * CW + (lane & (CW - 1));
         const int kphase = (wave % (kWaves / NCB)) * (64 / CW) + (lane / CW);
-        const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-        if (gi < G && gj < G && !cellSlow[cell] && !ABL(p, 8)) {
+        const int gi = cell_gi(cell), gj = cell_gj(cell);
+        if (cell_ok(cell) && !cellSlow[cell] && !ABL(p, 8)) {
             // one tap ROW (ky) at a time: the two D rows it needs are read once (2*PW LDS reads for D
             // outputs), the column fractions of the cell stay in registers
             const float *dc = dbuf + cell * DS;
@@ -552,8 +562,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, unsigned wid, un
     if (*nSlow != 0 && !ABL(p, 16)) {  // block-uniform, rare
         for (int cell = 0; cell < NC; ++cell) {
             if (!cellSlow[cell]) continue;
-            const int gi = ty * TH + (cell >> 4), gj = tx * kTileW + (cell & 15);
-            if (gi >= G || gj >= G) continue;
+            const int gi = cell_gi(cell), gj = cell_gj(cell);
+            if (!cell_ok(cell)) continue;
             for (int k = tid; k < K; k += kThreads)
                 p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
                     tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
@@ -574,17 +584,29 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
         }
     }
 #endif
-    process_tile<R, ROUNDS, true>(p, gfn::xcd_remap(blockIdx.x, gridDim.x), smem);
+    const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int b = wid / tiles, tile = wid - b * tiles;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    process_tile<R, ROUNDS, true, kTileW, false>(p, b, ty * 2 * ROUNDS, tx * kTileW, 2 * ROUNDS, wid, smem);
 }
 
-// second launch: the tiles the staged kernel left in p.todo (their number is only known on the device)
+// second launch: the tiles the staged kernel left in p.todo (their number is only known on the
+// device), re-cut into sub-tiles 8 cells wide and up to 4 rows high
 template <int R, int ROUNDS>
 __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n = p.todo[0];
+    constexpr int TH = 2 * ROUNDS, SH = TH < 4 ? TH : 4;  // sub-tile height
+    constexpr int SUBS = (TH / SH) * (kTileW / 8);
+    const int n = p.todo[0] * SUBS;
+    const int tiles = p.tiles_x * p.tiles_y;
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
-        process_tile<R, ROUNDS, false>(p, (unsigned)p.todo[1 + it], smem);
-        __syncthreads();  // LDS is reused by the next tile
+        const unsigned wid = (unsigned)p.todo[1 + it / SUBS];
+        const int sub = it % SUBS;
+        const int b = wid / tiles, tile = wid - b * tiles;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        process_tile<R, 1, true, 8, true>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
+        __syncthreads();  // LDS is reused by the next sub-tile
     }
 }
 
@@ -669,8 +691,8 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     if (fast_ok) {
         int rc = -1000;
         switch (r) {
-            case 1: rc = launch_tile<1, 4>(p, s); break;
-            case 2: rc = launch_tile<2, 4>(p, s); break;
+            case 1: rc = launch_tile<1, 2>(p, s); break;
+            case 2: rc = launch_tile<2, 2>(p, s); break;
             case 3: rc = launch_tile<3, 2>(p, s); break;
             case 4: rc = launch_tile<4, 2>(p, s); break;
             case 5: rc = launch_tile<5, 1>(p, s); break;

@@ -156,3 +156,17 @@ def test_errors_are_python_exceptions():
         local_correlation((1, 16, 8, 8), f0, f1, 2, 5, flow=torch.zeros(1, 2, 5, 5, device="cuda"))
     with pytest.raises(RuntimeError):
         local_correlation((1, 16, 8, 8), f0.cpu(), f1.cpu(), 2, 4, flow=torch.zeros(1, 2, 4, 4))
+
+
+# BASELINE config 3: googlemap 672x672 (pyramid sides 48/84/168/336, grids 48/48/96/192) -- larger maps,
+# grids that are not multiples of the tile, second-level (sub-tile) staging under strong zoom
+@pytest.mark.parametrize("c,hs,G,r", [(64, 48, 48, 7), (64, 84, 48, 6), (32, 168, 96, 4), (16, 336, 192, 2)])
+def test_config3_672_shapes_vs_oracle(c, hs, G, r):
+    B = 2
+    f0 = synth.lattice_normalish((B, c, G, G), 131 + r)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 132 + r)
+    flow = synth.homography_flow(B, G, 133, scale=1.0)
+    flow[1] = synth.homography_flow(1, G, 134, scale=1.45)[0] * np.float32(0.8)  # strong zoom: sub-tile / gather paths
+    out = run(f0, f1, flow, r, G)
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    assert_close(out, ref, TOL, f"672: c{c} hs{hs} G{G} r{r}")
