@@ -272,7 +272,8 @@ def main():
                    "excluded": "DINOv2/FPN backbone and refiner conv stacks (PyTorch-ROCm host code); stand-in increment = "
                                "exact residual to the true warp (2 torch elementwise ops per refiner call)",
                    "parallelism": f"pairs sharded over {world} GPU(s), RCCL all-gather of H only"},
-        "roofline": {"bound": "hbm", "kernel": "local_corr_tile_kernel<4,2> (c32, 112x112, G64, r4, 64 directions)",
+        "roofline": {"bound": "hbm", "kernel": "gfn_local_corr_fwd call = local_corr_tile_kernel<4,2> + local_corr_irregular_kernel<4,2> "
+                                               "(c32, 112x112, G64, r4, 64 directions)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kern_us, 2)},
