@@ -32,7 +32,8 @@ class ConvRefiner(nn.Module):
     """Per-scale refiner (reference: model/network.py:444-564).
 
     forward(num_grid, x, y, flow, scale_factor=1, logits=None) -> (delta_flow, delta_certainty,
-    local_corr).  Input assembly (network.py:533-558) is fused in HIP; the conv stack is torch.
+    local_corr).  Input assembly (network.py:533-558) and, in eval mode, the conv stack
+    (network.py:560-563) run in HIP; training mode keeps the nn modules.
     """
 
     def __init__(self, in_dim=6, hidden_dim=16, out_dim=2, dw=False, kernel_size=5, hidden_blocks=3,
@@ -65,6 +66,9 @@ class ConvRefiner(nn.Module):
         self.amp = amp
         self.amp_dtype = amp_dtype
         self.sample_mode = sample_mode
+        # "hip": eval-mode conv stack on csrc/conv_stack.hip (fp32, BatchNorm folded); "torch": nn modules
+        # under autocast as in the reference (always used in training mode)
+        self.conv_impl = "hip"
 
     def assemble(self, num_grid, x, y, flow, scale_factor=1):
         """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view."""
@@ -77,11 +81,56 @@ class ConvRefiner(nn.Module):
                               self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr)
         return d, (d[:, 2 * c + dd:] if use_corr else None)
 
+    # ---- conv stack in HIP (eval mode): BatchNorm folded, fp32 (csrc/conv_stack.hip) ----------------
+    def _hip_stack_supported(self):
+        if self.training or self.conv_impl != "hip":
+            return False
+        for blk in [self.block1] + list(self.hidden_blocks):
+            conv, norm, _, pw = blk
+            if not isinstance(norm, nn.BatchNorm2d) or conv.groups != conv.in_channels or conv.out_channels != conv.in_channels \
+                    or conv.kernel_size != (5, 5) or pw.in_channels != conv.out_channels:
+                return False
+        return True
+
+    def folded_stack(self):
+        """Per block the packed parameters of ops.conv_block (eval-mode BatchNorm folded to
+        y = x*alpha + beta in float64), and out_conv's (W, bias); cached until a parameter or running
+        statistic changes."""
+        blocks = [self.block1] + list(self.hidden_blocks)
+        key = tuple(t._version for blk in blocks for t in list(blk.parameters()) + list(blk.buffers())) + \
+            tuple(p._version for p in self.out_conv.parameters()) + (str(self.out_conv.weight.device),)
+        if getattr(self, "_fold_key", None) == key:
+            return self._fold
+        fold = []
+        with torch.no_grad():
+            for conv, norm, _, pw in blocks:
+                alpha = (norm.weight.double() / torch.sqrt(norm.running_var.double() + norm.eps)).float()
+                beta = (norm.bias.double() - norm.running_mean.double() * alpha.double()).float()
+                fold.append((ops.conv_block_pack(conv.weight, conv.bias, alpha, beta, pw.weight, pw.bias), pw.out_channels))
+            oc = self.out_conv
+            out = (oc.weight.float().reshape(oc.out_channels, oc.in_channels).contiguous(), oc.bias.float().contiguous())
+        self._fold_key, self._fold = key, (fold, out)
+        return self._fold
+
+    def conv_stack(self, d, variant=0):
+        """out_conv(hidden_blocks(block1(d))), network.py:560-563, on csrc/conv_stack.hip: one fused
+        kernel per block, two ping-pong maps."""
+        fold, (ow, ob) = self.folded_stack()
+        x, bufs = d, [None, None]
+        for i, (packed, M) in enumerate(fold):
+            if bufs[i & 1] is None or bufs[i & 1].shape[1] != M:
+                bufs[i & 1] = torch.empty((d.shape[0], M) + tuple(d.shape[2:]), device=d.device, dtype=torch.float32)
+            x = ops.conv_block(x, packed, M, out=bufs[i & 1], variant=variant)
+        return ops.pointwise_conv(x, ow, ob)
+
     def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None):
         d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor)
-        with torch.autocast("cuda", enabled=bool(self.amp), dtype=self.amp_dtype):
-            h = self.hidden_blocks(self.block1(d))
-        out = self.out_conv(h.float())
+        if self._hip_stack_supported():
+            out = self.conv_stack(d)
+        else:
+            with torch.autocast("cuda", enabled=bool(self.amp), dtype=self.amp_dtype):
+                h = self.hidden_blocks(self.block1(d))
+            out = self.out_conv(h.float())
         return out[:, :2], out[:, 2:3], local_corr
 
 

@@ -290,3 +290,50 @@ def homography_dlt(pts, weight=None):
     ok = torch.empty((Bt,), device=dev, dtype=torch.int32)
     check(_L().gfn_homography_dlt(ptr(p), ptr(w), Bt, N, ptr(H), ptr(ok), stream_ptr(dev)), "gfn_homography_dlt")
     return H, ok
+
+
+def conv_block_pack(dw_w, dw_b, bn_alpha, bn_beta, pw_w, pw_b):
+    """Pack one ConvRefiner block (model/network.py:471-487) for conv_block: dw_w (C,25) or (C,1,5,5),
+    dw_b (C) or None, eval-mode BatchNorm as y = x*alpha + beta, pw_w (M,C[,1,1]), pw_b (M)."""
+    dev = require_gpu(dw_w, pw_w)
+    C, M = dw_w.shape[0], pw_w.shape[0]
+    dw_w, pw_w = f32c(dw_w.reshape(C, 25)), f32c(pw_w.reshape(M, C))
+    al, be, pb = f32c(bn_alpha), f32c(bn_beta), f32c(pw_b)
+    db = f32c(dw_b) if dw_b is not None else None
+    packed = torch.empty(int(_L().gfn_conv_block_packed_floats(C, M)), device=dev, dtype=torch.float32)
+    check(_L().gfn_conv_block_pack(ptr(dw_w), ptr(db) if db is not None else None, ptr(al), ptr(be), ptr(pw_w), ptr(pb), ptr(packed),
+                                   C, M, stream_ptr(dev)), "gfn_conv_block_pack")
+    return packed
+
+
+def conv_block(x, packed, M, out=None, variant=0, t_scratch=None):
+    """Conv2d(C,C,5,pad 2,groups=C) -> BatchNorm2d(eval) -> ReLU -> Conv2d(C,M,1) in one kernel
+    (model/network.py:471-487).  variant=1 forces the two-pass form (bit-identical)."""
+    dev = require_gpu(x, packed)
+    x = f32c(x)
+    B, C, G, G2 = x.shape
+    if G != G2:
+        raise ValueError("conv_block: square grids only")
+    if packed.numel() != int(_L().gfn_conv_block_packed_floats(C, M)):
+        raise ValueError("conv_block: packed parameters do not match (C=%d, M=%d)" % (C, M))
+    if out is None:
+        out = torch.empty((B, M, G, G), device=dev, dtype=torch.float32)
+    if (variant == 1 or G % 4) and t_scratch is None:
+        t_scratch = torch.empty_like(x)
+    check(_timed("conv_block_c%d_g%d" % (C, G), lambda: _L().gfn_conv_block_fwd(
+        ptr(x), ptr(packed), ptr(out), ptr(t_scratch) if t_scratch is not None else None, B, C, M, G, int(variant),
+        stream_ptr(dev))), "gfn_conv_block_fwd")
+    return out
+
+
+def pointwise_conv(t, w, bias, out=None):
+    """Conv2d(K, M, 1)(t) for a few output channels: out_conv (model/network.py:505,563).  w (M,K)."""
+    dev = require_gpu(t, w)
+    t, w, bias = f32c(t), f32c(w), f32c(bias)
+    B, K, G, G2 = t.shape
+    M = bias.shape[0]
+    if out is None:
+        out = torch.empty((B, M, G, G2), device=dev, dtype=torch.float32)
+    check(_timed("pw_m%d_k%d_g%d" % (M, K, G), lambda: _L().gfn_pointwise_conv_fwd(
+        ptr(w), ptr(bias), ptr(t), ptr(out), B, M, K, G * G2, stream_ptr(dev))), "gfn_pointwise_conv_fwd")
+    return out

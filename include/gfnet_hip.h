@@ -193,6 +193,30 @@ int gfn_homography_ransac(const float *pts, int Bt, int N, double thresh, int it
                           gfn_stream_t stream);
 int gfn_homography_dlt(const float *pts, const float *weight, int Bt, int N, double *H, int *ok, gfn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Refiner conv stack -- ConvRefiner.create_block / forward, model/network.py:471-487
+ * and :560-563: nine blocks of depthwise 5x5 conv -> BatchNorm2d(eval) -> ReLU -> 1x1 conv, then a
+ * final 1x1 conv to 3 channels.  fp32 throughout (fp32 matrix-core products and accumulation).
+ *
+ * gfn_conv_block_pack: lays one block's parameters out for the kernels (device to device):
+ *   dw_w (C,25) depthwise taps, dw_b (C) or NULL, bn_alpha/bn_beta (C) the eval-mode BatchNorm as
+ *   y = x*alpha + beta (alpha = weight/sqrt(running_var+eps), beta = bias - running_mean*alpha),
+ *   pw_w (M,C) and pw_b (M) the 1x1 conv; packed: gfn_conv_block_packed_floats(C, M) floats.
+ * gfn_conv_block_fwd: y = pw(relu(bn(dw(x)))) for x (B,C,G,G) -> y (B,M,G,G), zero padding 2; y must
+ *   not alias x.  variant 0: one fused kernel when G % 4 == 0, otherwise the two-pass form;
+ *   variant 1: always two-pass (depthwise kernel -> t_scratch (B*C*G*G floats) -> GEMM kernel);
+ *   both give bit-identical results.  t_scratch may be NULL when the fused kernel applies.
+ * gfn_pointwise_conv_fwd: y[b] = W . t[b] + bias for a few output channels (M <= 16; the final C -> 3
+ *   conv, network.py:505,563): w (M,K), t (B,K,N), y (B,M,N).
+ */
+int64_t gfn_conv_block_packed_floats(int C, int M);
+int gfn_conv_block_pack(const float *dw_w, const float *dw_b, const float *bn_alpha, const float *bn_beta, const float *pw_w,
+                        const float *pw_b, float *packed, int C, int M, gfn_stream_t stream);
+int gfn_conv_block_fwd(const float *x, const float *packed, float *y, float *t_scratch, int B, int C, int M, int G, int variant,
+                       gfn_stream_t stream);
+int gfn_pointwise_conv_fwd(const float *w, const float *bias, const float *t, float *y, int B, int M, int K, int N,
+                           gfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

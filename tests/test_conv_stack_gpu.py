@@ -1,0 +1,124 @@
+"""GPU: the refiner conv stack (csrc/conv_stack.hip) against torch's convs of the same
+layers (model/network.py:471-487, 560-563) through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _maxerr(a, b):
+    return float((a.double() - b.double()).abs().max()), float(b.double().abs().max())
+
+
+def _block_case(B, C, M, G, bias=True):
+    x = _rand(B, C, G, G, seed=1)
+    w = _rand(C, 1, 5, 5, seed=2, scale=0.3)
+    cb = _rand(C, seed=3) if bias else None
+    gamma, beta_bn = _rand(C, seed=4).abs() + 0.5, _rand(C, seed=5)
+    mean, var = _rand(C, seed=6), _rand(C, seed=7).abs() + 0.1
+    pw = _rand(M, C, seed=8, scale=C ** -0.5)
+    pb = _rand(M, seed=9)
+    eps = 1e-5
+    t = F.relu(F.batch_norm(F.conv2d(x.double(), w.double(), cb.double() if bias else None, padding=2, groups=C), mean.double(),
+                            var.double(), gamma.double(), beta_bn.double(), False, 0.0, eps))
+    want = F.conv2d(t, pw.double().reshape(M, C, 1, 1), pb.double())
+    alpha = (gamma.double() / torch.sqrt(var.double() + eps)).float()
+    beta = (beta_bn.double() - mean.double() * alpha.double()).float()
+    return x, (w, cb, alpha, beta, pw, pb), want
+
+
+# (B, C, M, G): the five refiner widths, every tile shape (G % 32 == 0 -> 4x32 cells, G % 16 -> 8x16,
+# else 16x8), ragged channel counts, partial edge tiles, G not a multiple of 4 (two-pass form)
+CASES = [(2, 24, 24, 64), (1, 73, 73, 40), (1, 417, 417, 32), (1, 361, 361, 16), (1, 177, 177, 80), (3, 5, 9, 8), (2, 8, 8, 4),
+         (1, 33, 70, 12), (1, 24, 24, 160), (2, 16, 16, 20), (1, 225, 100, 24), (2, 22, 22, 10), (1, 7, 7, 5), (1, 40, 33, 48)]
+
+
+@pytest.mark.parametrize("B,C,M,G", CASES)
+def test_conv_block_matches_torch_float64(B, C, M, G):
+    from gfnet_amd import ops
+
+    x, (w, cb, alpha, beta, pw, pb), want = _block_case(B, C, M, G, bias=(C % 2 == 1))
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    got = ops.conv_block(x, packed, M)
+    assert got.shape == want.shape
+    err, mag = _maxerr(got, want)
+    assert err <= 1e-5 * max(mag, 1.0), (err, mag)  # fp32 fma chains (25 taps, then K products) vs float64
+    two_pass = ops.conv_block(x, packed, M, variant=1)
+    assert torch.equal(got, two_pass), "fused and two-pass kernels must agree bit for bit"
+
+
+@pytest.mark.parametrize("B,M,K,G", [(3, 3, 24, 16), (2, 3, 417, 8), (1, 5, 7, 5), (1, 1, 3, 4)])
+def test_pointwise_conv_matches_torch(B, M, K, G):
+    from gfnet_amd import ops
+
+    t = _rand(B, K, G, G, seed=11)
+    w = _rand(M, K, seed=12, scale=K ** -0.5)
+    b = _rand(M, seed=13)
+    want = F.conv2d(t.double(), w.double().reshape(M, K, 1, 1), b.double())
+    got = ops.pointwise_conv(t, w, b)
+    err, mag = _maxerr(got, want)
+    assert got.shape == want.shape and err <= 1e-5 * max(mag, 1.0), (err, mag)
+
+
+def test_conv_block_rejects_bad_arguments():
+    from gfnet_amd import ops
+    from gfnet_amd._lib import GfnError
+
+    x, (w, cb, alpha, beta, pw, pb), _ = _block_case(1, 8, 8, 8)
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    with pytest.raises(GfnError):
+        ops.conv_block(x, packed, 8, out=x)  # in place
+    with pytest.raises(ValueError):
+        ops.conv_block(x, packed, 40)  # packed for another shape
+    with pytest.raises(GfnError):
+        ops.pointwise_conv(x, _rand(17, 8), _rand(17))  # too many outputs for the small-M kernel
+
+
+@pytest.mark.parametrize("feat,disp,r,G,B", [(8, 8, 0, 64, 3), (16, 16, 2, 32, 2), (32, 32, 4, 16, 2), (64, 64, 7, 8, 1),
+                                             (64, 64, 6, 40, 1)])
+def test_conv_stack_matches_torch_modules(feat, disp, r, G, B):
+    """The whole stack of a real refiner configuration (random BatchNorm statistics) against the
+    same nn modules run by torch in fp32 (MIOpen/ATen)."""
+    from gfnet_amd.model.network import _refiner_for
+
+    torch.manual_seed(5)
+    ref = _refiner_for(feat, disp, r).cuda().eval()
+    ref.amp = False
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    C = ref.block1[0].in_channels
+    d = _rand(B, C, G, G, seed=21)
+    with torch.no_grad():
+        want = ref.out_conv(ref.hidden_blocks(ref.block1(d.clone())))
+        got = ref.conv_stack(d)
+        got2 = ref.conv_stack(d, variant=1)
+    err, mag = _maxerr(got, want)
+    assert err <= 1e-4 * max(mag, 1.0), (err, mag)
+    assert torch.equal(got, got2)
+    # a changed running statistic invalidates the folded parameters
+    with torch.no_grad():
+        ref.block1[1].running_mean.add_(0.5)
+        assert not torch.equal(ref.conv_stack(d), got)
+
+
+def test_training_mode_uses_torch_modules():
+    from gfnet_amd.model.network import _refiner_for
+
+    ref = _refiner_for(8, 8, 0).cuda()
+    ref.train()
+    assert not ref._hip_stack_supported()
+    ref.eval()
+    assert ref._hip_stack_supported()
+    ref.conv_impl = "torch"
+    assert not ref._hip_stack_supported()
