@@ -23,22 +23,33 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kKT = 16;    // channels per K tile
-constexpr int kBN = 128;   // cells per workgroup: 4 waves x 32
-constexpr int kCP = 48;    // floats per channel in the packed depthwise parameters: 5 tap rows of 8 (5 used), bias, alpha, beta at 40..42
+constexpr int kNP = 8;     // channel pairs per K tile
+constexpr int kBN = 128;   // cells per workgroup tile: 4 waves x 32
+constexpr int kCP2 = 64;   // floats per channel PAIR in the packed depthwise parameters
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- packed parameters of one block ---------------------------------------------------------------
-// [ cp: Kp x 48 ][ wt: Kp x Mp (W transposed, zero padded) ][ bias: Mp ],  Kp = ceil16(C), Mp = ceil32(M)
+// [ cp: Kp/2 x 64 ][ wt: Kp x Mp weights, zero padded, in MFMA operand order ][ bias: Mp ],  Kp = ceil16(C), Mp = ceil32(M)
+// wt: W[m][k] sits at wt_index(k, m): per K tile of 16 the order is [k half sg][k parity kh][m][j], k = 16*kt + 8*sg + 2*j + kh,
+// so that one 16-byte LDS read hands a lane its A operands of four consecutive MFMA k-steps.
+// cp row of channel pair (2p, 2p+1): float 2t+h = parameter t of channel 2p+h; t = 0..24 the 5x5 taps
+// (row major), 25 = conv bias, 26 = alpha, 27 = beta -- the layout the packed-fp32 (v_pk_fma_f32)
+// depthwise loop reads as register pairs.
 struct PackDims {
     int Kp, Mp;
     __host__ __device__ PackDims(int C, int M) : Kp(round_up(C, kKT)), Mp(round_up(M, 32)) {}
     __host__ __device__ size_t cp_off() const { return 0; }
-    __host__ __device__ size_t wt_off() const { return (size_t)Kp * kCP; }
+    __host__ __device__ size_t wt_off() const { return (size_t)(Kp / 2) * kCP2; }
     __host__ __device__ size_t bias_off() const { return wt_off() + (size_t)Kp * Mp; }
     __host__ __device__ size_t total() const { return bias_off() + Mp; }
+    __host__ __device__ size_t wt_index(int k, int m) const {
+        const int kt = k >> 4, r = k & 15, sg = r >> 3, kh = r & 1, j = (r & 7) >> 1;
+        return ((size_t)((kt * 2 + sg) * 2 + kh) * Mp + m) * 4 + j;
+    }
 };
 
 __global__ __launch_bounds__(256) void pack_block_kernel(const float *__restrict__ dw_w, const float *__restrict__ dw_b,
@@ -50,16 +61,18 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const float *__restrict
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         if (i < d.wt_off()) {
-            const int k = (int)(i / kCP), j = (int)(i % kCP);
+            const int pair = (int)(i / kCP2), j = (int)(i % kCP2);
+            const int t = j >> 1, k = 2 * pair + (j & 1);
             if (k < C) {
-                if (j < 40) v = (j & 7) < 5 ? dw_w[(size_t)k * 25 + (j >> 3) * 5 + (j & 7)] : 0.f;
-                else if (j == 40) v = dw_b ? dw_b[k] : 0.f;
-                else if (j == 41) v = alpha[k];
-                else if (j == 42) v = beta[k];
+                if (t < 25) v = dw_w[(size_t)k * 25 + t];
+                else if (t == 25) v = dw_b ? dw_b[k] : 0.f;
+                else if (t == 26) v = alpha[k];
+                else if (t == 27) v = beta[k];
             }
         } else if (i < d.bias_off()) {
-            const size_t e = i - d.wt_off();
-            const int k = (int)(e / d.Mp), m = (int)(e % d.Mp);
+            const size_t e = i - d.wt_off();  // invert wt_index
+            const int j = (int)(e & 3), m = (int)((e >> 2) % d.Mp), g = (int)((e >> 2) / d.Mp);
+            const int k = (g >> 2) * 16 + ((g >> 1) & 1) * 8 + 2 * j + (g & 1);
             if (k < C && m < M) v = pw_w[(size_t)m * C + k];
         } else {
             const int m = (int)(i - d.bias_off());
@@ -73,165 +86,129 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const float *__restrict
 // output in (dy, dx) order, then (acc + bias) * alpha + beta, relu.
 __device__ __forceinline__ float dw_finish(float acc, float cb, float al, float be) { return fmaxf((acc + cb) * al + be, 0.f); }
 
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2 be) {
+    f32x2 r;
+    r.x = dw_finish(acc.x, cb.x, al.x, be.x);
+    r.y = dw_finish(acc.y, cb.y, al.y, be.y);
+    return r;
+}
+
 // ---- fused block ------------------------------------------------------------------------------------
-// Persistent workgroups walk a contiguous run of work items (cell tile x output slab); the (item,
-// K tile) pairs form one software pipeline:  global loads run three steps ahead (registers), the LDS
-// commit two, the depthwise arithmetic one step ahead of the matrix-core step it feeds, so every wave
-// interleaves VALU (depthwise for step i+1) with MFMA (step i) and no load latency is exposed.
-template <int TW>
-struct FusedGeom {
-    static constexpr int TH = kBN / TW;       // tile rows
-    static constexpr int HR = TH + 4;         // halo rows
-    static constexpr int RV4 = (TW + 8) / 4;  // float4 per staged halo row: columns col0-4 .. col0+TW+3
-    static constexpr int RP = TW + 8 + 4;     // LDS row pitch (floats): +4 spreads the b128 reads of a 16-lane group
-    static constexpr int CPITCH = HR * RP;
-    static constexpr int XV4 = kKT * HR * RV4;  // float4 of one halo stage
-    static constexpr int XPT = (XV4 + 255) / 256;
-    static constexpr int OPR = TW / 8;        // 8-cell groups per tile row
-};
+// Workgroup = NS*4 waves on one 128-cell tile of one map and NS slabs of 32*MT output channels (the
+// waves of both slabs share the depthwise work and the B operand tile).  Per K tile of 16 channels:
+//   commit   registers -> LDS: the tile's halo, channel-pair interleaved ([pair][row][cell][2]), the weight
+//            tile W^T[k][m], the pairs' depthwise parameters        | barrier
+//   issue    global loads of the NEXT K tile into registers (land under the arithmetic below)
+//   depthwise  per thread 4/NS cells x one channel pair on packed fp32 (v_pk_fma_f32), relu, into the
+//            B operand tile Bs[pair][cell][2]                        | barrier
+//   matrix   8 k-steps x MT v_mfma_f32_32x32x2_f32 per wave
+// Halo cells outside the map are zeroed once in LDS and never written (zero padding for free).
+template <int MT, int TW, int NS>
+__global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(const float *__restrict__ x,
+                                                                               const float *__restrict__ packed,
+                                                                               float *__restrict__ y, int M, int K, int G,
+                                                                               int tiles_x, int tiles_y, int ngrp, unsigned nwork) {
+    constexpr int NT = 256 * NS;
+    constexpr int TH = kBN / TW;            // tile rows
+    constexpr int HR = TH + 4;              // halo rows
+    constexpr int RV4 = (TW + 8) / 4;       // float4 per staged halo row and channel: cells col0-4 .. col0+TW+3
+    constexpr int RPP = (TW + 8) * 2 + 4;   // LDS floats per halo row of a channel pair (+4: bank spread)
+    constexpr int PP = HR * RPP;            // LDS floats per channel pair
+    constexpr int PS = kNP * HR * RV4;      // staging slots: one = the same 4 cells of both channels of a pair
+    constexpr int XPP = (PS + NT - 1) / NT;
+    constexpr int BM = 32 * MT, BMS = BM * NS;
+    constexpr int AV4 = 4 * BMS;            // float4 of one weight tile
+    constexpr int APT = (AV4 + NT - 1) / NT;
+    constexpr int PPT = kNP * kCP2 / NT;    // parameter floats per thread and K tile
+    constexpr int CPT = 4 / NS;             // depthwise: cells per thread
+    constexpr int TPP = kBN / CPT;          //            threads per channel pair
+    constexpr int GPR = TW / CPT;           //            threads per tile row
 
-template <int MT, int TW>
-__global__ __launch_bounds__(256, 2) void dwpw_fused_kernel(const float *__restrict__ x, const float *__restrict__ packed,
-                                                            float *__restrict__ y, int M, int K, int G, int tiles_x, int tiles_y,
-                                                            int nblk, unsigned nwork) {
-    using Geo = FusedGeom<TW>;
-    constexpr int TH = Geo::TH, HR = Geo::HR, RV4 = Geo::RV4, RP = Geo::RP, CPITCH = Geo::CPITCH, XV4 = Geo::XV4, XPT = Geo::XPT,
-                  OPR = Geo::OPR;
-    constexpr int BM = 32 * MT;
-    constexpr int AV4 = kKT * BM / 4;
-    constexpr int APT = (AV4 + 255) / 256;
-    constexpr int PPT = kKT * kCP / 256;  // parameter floats per thread and stage
-
-    __shared__ __attribute__((aligned(16))) float Xs[kKT * CPITCH];
-    __shared__ __attribute__((aligned(16))) float As[2][kKT][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kKT][kBN];
-    __shared__ __attribute__((aligned(16))) float Ps[kKT * kCP];
+    __shared__ __attribute__((aligned(16))) float Xs[kNP * PP];
+    __shared__ float4 As4[2][4 * BMS];  // [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3
+    __shared__ __attribute__((aligned(16))) float Bs[kNP * kBN * 2];
+    __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
 
     const PackDims pd(K, M);
     const float *cp = packed + pd.cp_off();
     const float *wt = packed + pd.wt_off();
     const float *bias = packed + pd.bias_off();
-    const int Mp = pd.Mp, nk = pd.Kp / kKT;
-    const size_t plane = (size_t)G * G;
+    const int Mp = pd.Mp, Kp = pd.Kp;
+    const int plane = G * G;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned lb = gfn::xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned w_begin = (unsigned)(((unsigned long long)lb * nwork) / gridDim.x);
-    const unsigned w_end = (unsigned)(((unsigned long long)(lb + 1) * nwork) / gridDim.x);
-    const int total = (int)(w_end - w_begin) * nk;  // pipeline steps of this workgroup
-    if (total <= 0) return;
+    unsigned L = gfn::xcd_remap(blockIdx.x, nwork);
+    const int grp = (int)(L % (unsigned)ngrp);
+    L /= (unsigned)ngrp;
+    const int tx = (int)(L % (unsigned)tiles_x);
+    L /= (unsigned)tiles_x;
+    const int ty = (int)(L % (unsigned)tiles_y);
+    const int b = (int)(L / (unsigned)tiles_y);
+    const int row0 = ty * TH, col0 = tx * TW, m0 = grp * BMS;
+    const float *xb = x + (size_t)b * K * plane;
 
-    auto decode = [&](unsigned item, int &b, int &row0, int &col0, int &m0) {
-        const unsigned mblk = item % (unsigned)nblk;
-        item /= (unsigned)nblk;
-        const unsigned tx = item % (unsigned)tiles_x;
-        item /= (unsigned)tiles_x;
-        const unsigned ty = item % (unsigned)tiles_y;
-        b = (int)(item / (unsigned)tiles_y);
-        row0 = (int)ty * TH, col0 = (int)tx * TW, m0 = (int)mblk * BM;
-    };
-
-    // ---- load stage state: which (item, K tile) the next issue() fetches
-    unsigned l_item = w_begin;
-    int l_kt = 0, l_m0 = 0;
-    const float *l_xb = x;
-    int xoff[XPT];
-    bool xok[XPT];
-    auto load_stage_enter_item = [&]() {
-        int b, row0, col0;
-        decode(l_item, b, row0, col0, l_m0);
-        l_xb = x + (size_t)b * K * plane;
+    // staging slots of this thread (fixed for the whole kernel)
+    int xg[XPP], xl[XPP], xp2[XPP];
+    bool xv[XPP];
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int e = tid + 256 * i;
-            const int ch = e / (HR * RV4), rem = e - ch * (HR * RV4);
-            const int hr = rem / RV4, q = rem - hr * RV4;
-            const int gy = row0 - 2 + hr, gx = col0 - 4 + 4 * q;
-            const bool ok = e < XV4 && (unsigned)gy < (unsigned)G && gx >= 0 && gx < G;  // G % 4 == 0: whole float4 in or out
-            xok[i] = ok;
-            xoff[i] = ok ? gy * G + gx : 0;
-        }
-    };
-    float4 xr[XPT], ar[APT];
+    for (int i = 0; i < XPP; ++i) {
+        const int e = tid + NT * i;
+        const int p = e / (HR * RV4), rem = e - p * (HR * RV4);
+        const int hr = rem / RV4, q = rem - hr * RV4;
+        const int gy = row0 - 2 + hr, gx = col0 - 4 + 4 * q;
+        xv[i] = e < PS && (unsigned)gy < (unsigned)G && gx >= 0 && gx < G;  // G % 4 == 0: the 4 cells are in or out together
+        xg[i] = xv[i] ? gy * G + gx : 0;
+        xp2[i] = 2 * p;
+        xl[i] = p * PP + hr * RPP + 8 * q;
+    }
+    for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    static_assert(APT <= 4, "weight tile slots");
+    float4 xr0[XPP], xr1[XPP];
+    float4 ar0, ar1, ar2, ar3;  // named, not an array: the compiler demotes a float4 array here to LDS
     float pr[PPT];
-    auto issue = [&]() {  // fetch (l_item, l_kt) into registers, then advance the load stage
-        const int k0 = l_kt * kKT;
+    const float4 *wt4 = reinterpret_cast<const float4 *>(wt);
+    auto a_load = [&](int k0, int i) {
+        const int e = tid + NT * i;
+        const int g = e / BMS, m = m0 + e - g * BMS;
+        const bool ok = e < AV4 && m < Mp;
+        return wt4[(size_t)((k0 >> 2) + (ok ? g : 0)) * Mp + (ok ? m : 0)];
+    };
+    auto a_store = [&](int buf, int i, const float4 &v) {
+        const int e = tid + NT * i;
+        if (e < AV4) As4[buf][e] = v;
+    };
+    auto issue = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int e = tid + 256 * i;
-            const int kk = k0 + e / (HR * RV4);
-            const bool ok = xok[i] && kk < K;
-            const float4 v = *reinterpret_cast<const float4 *>(l_xb + (size_t)(ok ? kk : 0) * plane + xoff[i]);
-            xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < XPP; ++i) {
+            const int c0 = min(k0 + xp2[i], K - 1), c1 = min(k0 + xp2[i] + 1, K - 1);  // past C: any finite data, its taps are 0
+            xr0[i] = *reinterpret_cast<const float4 *>(xb + c0 * plane + xg[i]);
+            xr1[i] = *reinterpret_cast<const float4 *>(xb + c1 * plane + xg[i]);
         }
+        if constexpr (APT > 0) ar0 = a_load(k0, 0);
+        if constexpr (APT > 1) ar1 = a_load(k0, 1);
+        if constexpr (APT > 2) ar2 = a_load(k0, 2);
+        if constexpr (APT > 3) ar3 = a_load(k0, 3);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + 256 * i;
-            const int k = e / (BM / 4), m4 = e - k * (BM / 4);
-            const int m = l_m0 + 4 * m4;
-            const bool ok = e < AV4 && m < Mp;
-            const float4 v = *reinterpret_cast<const float4 *>(wt + (size_t)(k0 + (ok ? k : 0)) * Mp + (ok ? m : 0));
-            ar[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)k0 * kCP + tid + 256 * i];
-        if (++l_kt == nk) {
-            l_kt = 0;
-            if (++l_item < w_end) load_stage_enter_item();
-        }
+        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int e = tid + 256 * i;
-            const int ch = e / (HR * RV4), rem = e - ch * (HR * RV4);
-            const int hr = rem / RV4, q = rem - hr * RV4;
-            if (e < XV4) *reinterpret_cast<float4 *>(&Xs[ch * CPITCH + hr * RP + 4 * q]) = xr[i];
-        }
+        for (int i = 0; i < XPP; ++i)
+            if (xv[i]) {
+                float4 lo, hi;
+                lo.x = xr0[i].x, lo.y = xr1[i].x, lo.z = xr0[i].y, lo.w = xr1[i].y;
+                hi.x = xr0[i].z, hi.y = xr1[i].z, hi.z = xr0[i].w, hi.w = xr1[i].w;
+                *reinterpret_cast<float4 *>(&Xs[xl[i]]) = lo;
+                *reinterpret_cast<float4 *>(&Xs[xl[i] + 4]) = hi;
+            }
+        if constexpr (APT > 0) a_store(buf, 0, ar0);
+        if constexpr (APT > 1) a_store(buf, 1, ar1);
+        if constexpr (APT > 2) a_store(buf, 2, ar2);
+        if constexpr (APT > 3) a_store(buf, 3, ar3);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + 256 * i;
-            const int k = e / (BM / 4), m4 = e - k * (BM / 4);
-            if (e < AV4) *reinterpret_cast<float4 *>(&As[buf][k][4 * m4]) = ar[i];
-        }
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) Ps[tid + 256 * i] = pr[i];
-    };
-
-    const int col = lane & 31, kh = lane >> 5;
-    // depthwise role: channel dk of the K tile, tile row dr, 8-cell group dg
-    const int dk = tid >> 4, dro = tid & 15, dr = dro / OPR, dg = dro - dr * OPR;
-    const float *dw_src = &Xs[dk * CPITCH + dr * RP + 8 * dg];  // halo columns 8dg .. 8dg+15 = cells 8dg-4 .. 8dg+11
-    const float *dw_par = &Ps[dk * kCP];
-    const int dw_dst = dk * kBN + dr * TW + 8 * dg;
-
-    // depthwise 5x5 + affine + relu for the staged K tile: 8 cells of one row of one channel into Bs[buf]
-    float a8[8];
-    auto dw_row = [&](int dy) {
-        const float4 w0 = *reinterpret_cast<const float4 *>(dw_par + 8 * dy);
-        const float w4 = dw_par[8 * dy + 4];
-        const float w[5] = {w0.x, w0.y, w0.z, w0.w, w4};
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 f = *reinterpret_cast<const float4 *>(dw_src + dy * RP + 4 * q);
-            v[4 * q] = f.x, v[4 * q + 1] = f.y, v[4 * q + 2] = f.z, v[4 * q + 3] = f.w;
-        }
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] = fmaf(w[dx], v[j + dx + 2], a8[j]);
-    };
-    auto dw_store = [&](int buf) {
-        const float cb = dw_par[40], al = dw_par[41], be = dw_par[42];
-        float4 o0, o1;
-        o0.x = dw_finish(a8[0], cb, al, be), o0.y = dw_finish(a8[1], cb, al, be);
-        o0.z = dw_finish(a8[2], cb, al, be), o0.w = dw_finish(a8[3], cb, al, be);
-        o1.x = dw_finish(a8[4], cb, al, be), o1.y = dw_finish(a8[5], cb, al, be);
-        o1.z = dw_finish(a8[6], cb, al, be), o1.w = dw_finish(a8[7], cb, al, be);
-        float *dst = &Bs[buf][0][0] + dw_dst;
-        *reinterpret_cast<float4 *>(dst) = o0;
-        *reinterpret_cast<float4 *>(dst + 4) = o1;
+        for (int i = 0; i < PPT; ++i) Ps[tid + NT * i] = pr[i];
     };
 
     f32x16 acc[MT];
@@ -240,67 +217,110 @@ __global__ __launch_bounds__(256, 2) void dwpw_fused_kernel(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // ---- prologue: step 0 staged and its depthwise done, step 1 staged, step 2 in registers
-    load_stage_enter_item();
-    issue();
-    commit(0);
-    __syncthreads();
-    if (total > 1) issue();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a8[j] = 0.f;
-#pragma unroll
-    for (int dy = 0; dy < 5; ++dy) dw_row(dy);
-    dw_store(0);
-    __syncthreads();
-    if (total > 1) commit(1);
-    if (total > 2) issue();
-    __syncthreads();
+    const int col = lane & 31, kh = lane >> 5;
+    const int slab = wave >> 2, cw = wave & 3;  // matrix role: output slab, 32-cell group
+    // depthwise role: channel pair dp, tile row dr, cells dc .. dc+CPT-1
+    const int dp = tid / TPP, dg = tid - dp * TPP, dr = dg / GPR, dc = (dg - dr * GPR) * CPT;
+    const float *dw_src = &Xs[dp * PP + dr * RPP + 2 * (dc + 2)];  // staged cell index = tile cell + 4; taps reach cells dc-2 ..
+    const f32x2 *dw_par = reinterpret_cast<const f32x2 *>(&Ps[dp * kCP2]);
+    float *dw_dst = &Bs[(dp * kBN + dr * TW + dc) * 2];
 
-    unsigned c_item = w_begin;  // MFMA stage
-    int c_kt = 0;
-    for (int it = 0; it < total; ++it) {
-        const int buf = it & 1;
-        // MFMA for step it (As[buf], Bs[buf]) interleaved with the depthwise of step it+1 (Xs -> Bs[buf^1]);
-        // past the last step the depthwise runs on stale data and its output is never read
+    issue(0);
+    __syncthreads();  // Xs zeroed
+    int buf = 0;
+    for (int k0 = 0; k0 < Kp; k0 += kKT, buf ^= 1) {
+        commit(buf);
+        __syncthreads();
+        if (k0 + kKT < Kp) issue(k0 + kKT);
+        {
+            f32x2 a[CPT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a8[j] = 0.f;
+            for (int j = 0; j < CPT; ++j) a[j] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < kKT / 2; ++s) {
-            const float bv = Bs[buf][2 * s + kh][wave * 32 + col];
+            for (int dy = 0; dy < 5; ++dy) {
+                f32x2 v[CPT + 4];
+#pragma unroll
+                for (int q = 0; q < (CPT + 4) / 2; ++q) {
+                    const float4 f = *reinterpret_cast<const float4 *>(dw_src + dy * RPP + 4 * q);
+                    v[2 * q] = f32x2{f.x, f.y};
+                    v[2 * q + 1] = f32x2{f.z, f.w};
+                }
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) {
+                    const f32x2 w = dw_par[dy * 5 + dx];
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) a[j] = pk_fma(w, v[j + dx], a[j]);
+                }
+            }
+            const f32x2 cb = dw_par[25], al = dw_par[26], be = dw_par[27];
+#pragma unroll
+            for (int j = 0; j < CPT; j += 2) {
+                const f32x2 t0 = dw_finish2(a[j], cb, al, be), t1 = dw_finish2(a[j + 1], cb, al, be);
+                *reinterpret_cast<float4 *>(dw_dst + 2 * j) = make_float4(t0.x, t0.y, t1.x, t1.y);
+            }
+        }
+        __syncthreads();
+        {   // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
+            // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
+            const float *bsrc = &Bs[(cw * 32 + col) * 2 + kh];  // t[2s+kh][cell] at + s*256
+            const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
+            float bv[8];
+            float4 av[MT];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) bv[s8] = bsrc[s8 * 2 * kBN];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const float av = As[buf][2 * s + kh][i * 32 + col];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
-            }
-            if (s < 5) dw_row(s);
-        }
-        dw_store(buf ^ 1);
-        if (++c_kt == nk) {  // item finished: D[row][col], col = lane&31 -> cell wave*32+col, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            int b, row0, col0, m0;
-            decode(c_item, b, row0, col0, m0);
-            const int p = wave * 32 + col;
-            const int gy = row0 + p / TW, gx = col0 + p % TW;
-            if (gy < G && gx < G) {
-                float *yb = y + (size_t)b * M * plane + (size_t)gy * G + gx;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                        if (m < M) yb[(size_t)m * plane] = acc[i][r] + bias[m];
-                    }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[3], acc[i], 0, 0, 0);
+                av[i] = asrc[2 * BMS + i * 32];
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            c_kt = 0;
-            ++c_item;
+            for (int i = 0; i < MT; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[4], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[5], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[6], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[7], acc[i], 0, 0, 0);
+            }
         }
-        __syncthreads();
-        if (it + 2 < total) commit(buf);
-        if (it + 3 < total) issue();
-        __syncthreads();
+    }
+    // D[row][col]: col = lane&31 -> cell cw*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int p = cw * 32 + col;
+    const int gy = row0 + p / TW, gx = col0 + p % TW;
+    if (gy < G && gx < G) {
+        float *yb = y + (size_t)b * M * plane + (size_t)gy * G + gx;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + slab * BM + i * 32;  // 32 output channels of this accumulator tile
+            if (mb >= M) break;
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4 *>(bias + mb + 8 * q + 4 * kh);  // bias is padded to Mp
+            float *yt = yb + (size_t)(mb + 4 * kh) * plane;
+            if (mb + 32 <= M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    yt[(size_t)(8 * q) * plane] = acc[i][4 * q] + bq[q].x;
+                    yt[(size_t)(8 * q + 1) * plane] = acc[i][4 * q + 1] + bq[q].y;
+                    yt[(size_t)(8 * q + 2) * plane] = acc[i][4 * q + 2] + bq[q].z;
+                    yt[(size_t)(8 * q + 3) * plane] = acc[i][4 * q + 3] + bq[q].w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mb + 8 * q + 4 * kh;
+                    if (m < M) yt[(size_t)(8 * q) * plane] = acc[i][4 * q] + bq[q].x;
+                    if (m + 1 < M) yt[(size_t)(8 * q + 1) * plane] = acc[i][4 * q + 1] + bq[q].y;
+                    if (m + 2 < M) yt[(size_t)(8 * q + 2) * plane] = acc[i][4 * q + 2] + bq[q].z;
+                    if (m + 3 < M) yt[(size_t)(8 * q + 3) * plane] = acc[i][4 * q + 3] + bq[q].w;
+                }
+            }
+        }
     }
 }
 
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(256) void dw5x5_kernel(const float *__restrict__ x,
     if (local >= G * GV) return;
     const int i = local / GV, jv = local - i * GV;
     const float *xp = x + (size_t)pl * G * G;
-    const float *wc = packed + (size_t)c * kCP;
+    const float *wc = packed + (size_t)(c >> 1) * kCP2 + (c & 1);  // parameter t of this channel at wc[2t]
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
@@ -338,20 +358,20 @@ __global__ __launch_bounds__(256) void dw5x5_kernel(const float *__restrict__ x,
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(wc[dy * 8 + dx], v[q + dx + 2], acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(wc[2 * (dy * 5 + dx)], v[q + dx + 2], acc[q]);
         } else {
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) {
                 const int xx = jv + dx - 2;
                 const bool ok = rok && (unsigned)xx < (unsigned)G;
                 const float xv = row[ok ? xx : 0];
-                acc[0] = fmaf(wc[dy * 8 + dx], ok ? xv : 0.f, acc[0]);
+                acc[0] = fmaf(wc[2 * (dy * 5 + dx)], ok ? xv : 0.f, acc[0]);
             }
         }
     }
     float *dst = t + (size_t)pl * G * G + (size_t)i * G + (size_t)jv * VEC;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) dst[q] = dw_finish(acc[q], wc[40], wc[41], wc[42]);
+    for (int q = 0; q < VEC; ++q) dst[q] = dw_finish(acc[q], wc[50], wc[52], wc[54]);
 }
 
 // y[b] = W . t[b] + bias on the fp32 matrix core; same k order as the fused kernel.
@@ -375,12 +395,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const float *__restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     for (int k0 = 0; k0 < Kp; k0 += kKT) {
-        for (int e = tid; e < kKT * (BM / 4); e += 256) {
-            const int k = e / (BM / 4), m4 = e - k * (BM / 4);
-            const int m = m0 + m4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < Mp) v = *reinterpret_cast<const float4 *>(wt + (size_t)(k0 + k) * Mp + m);
-            *reinterpret_cast<float4 *>(&As[k][m4 * 4]) = v;
+        for (int e = tid; e < kKT * BM; e += 256) {
+            const int k = e / BM, mm = e - k * BM;
+            As[k][mm] = m0 + mm < Mp ? wt[pd.wt_index(k0 + k, m0 + mm)] : 0.f;
         }
         for (int e = tid; e < kKT * (kBN / 4); e += 256) {
             const int k = e / (kBN / 4), n4 = e - k * (kBN / 4);
@@ -459,38 +476,41 @@ inline void slab_shape(int M, int *nblk, int *mt) {
     *mt = (tiles + *nblk - 1) / *nblk;
 }
 
-template <int MT, int TW>
-int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int nblk, hipStream_t s) {
+template <int MT, int TW, int NS>
+int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
     constexpr int TH = kBN / TW;
     const int tiles_x = (G + TW - 1) / TW, tiles_y = (G + TH - 1) / TH;
-    const long nwork = (long)B * tiles_x * tiles_y * nblk;
+    const int ngrp = (M + 32 * MT * NS - 1) / (32 * MT * NS);
+    const long nwork = (long)B * tiles_x * tiles_y * ngrp;
     if (nwork > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: too many tiles");
-    // persistent workgroups: as many as the chip holds at once
-    static int resident = 0;  // per instantiation
-    if (!resident) {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dwpw_fused_kernel<MT, TW>, 256, 0) != hipSuccess || cus <= 0 ||
-            per_cu <= 0)
-            return gfn::fail(GFN_ERR_LAUNCH, "conv_block: occupancy query failed");
-        resident = cus * per_cu;
-    }
-    const unsigned grid = (unsigned)(nwork < resident ? nwork : resident);
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW>), dim3(grid), dim3(256), 0, s, x, packed, y, M, K, G, tiles_x, tiles_y, nblk,
-                       (unsigned)nwork);
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
+                       tiles_y, ngrp, (unsigned)nwork);
     return gfn::check_launch("dwpw_fused_kernel");
 }
 
+// output channels: one workgroup computes all of them where they fit 2 slabs of <= 7 MFMA row tiles
+// (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once
 template <int TW>
-int launch_fused(int mt, const float *x, const float *packed, float *y, int B, int M, int K, int G, int nblk, hipStream_t s) {
+int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
+    const int tiles = (M + 31) / 32;
+    if (tiles <= 7) {
+        switch (tiles) {
+            case 1: return launch_fused_mt<1, TW, 1>(x, packed, y, B, M, K, G, s);
+            case 2: return launch_fused_mt<2, TW, 1>(x, packed, y, B, M, K, G, s);
+            case 3: return launch_fused_mt<3, TW, 1>(x, packed, y, B, M, K, G, s);
+            case 4: return launch_fused_mt<4, TW, 1>(x, packed, y, B, M, K, G, s);
+            case 5: return launch_fused_mt<5, TW, 1>(x, packed, y, B, M, K, G, s);
+            case 6: return launch_fused_mt<6, TW, 1>(x, packed, y, B, M, K, G, s);
+            default: return launch_fused_mt<7, TW, 1>(x, packed, y, B, M, K, G, s);
+        }
+    }
+    const int ngrp = (tiles + 13) / 14;
+    const int mt = ((tiles + ngrp - 1) / ngrp + 1) / 2;  // row tiles per slab
     switch (mt) {
-        case 1: return launch_fused_mt<1, TW>(x, packed, y, B, M, K, G, nblk, s);
-        case 2: return launch_fused_mt<2, TW>(x, packed, y, B, M, K, G, nblk, s);
-        case 3: return launch_fused_mt<3, TW>(x, packed, y, B, M, K, G, nblk, s);
-        case 4: return launch_fused_mt<4, TW>(x, packed, y, B, M, K, G, nblk, s);
-        case 5: return launch_fused_mt<5, TW>(x, packed, y, B, M, K, G, nblk, s);
-        case 6: return launch_fused_mt<6, TW>(x, packed, y, B, M, K, G, nblk, s);
-        default: return launch_fused_mt<7, TW>(x, packed, y, B, M, K, G, nblk, s);
+        case 4: return launch_fused_mt<4, TW, 2>(x, packed, y, B, M, K, G, s);
+        case 5: return launch_fused_mt<5, TW, 2>(x, packed, y, B, M, K, G, s);
+        case 6: return launch_fused_mt<6, TW, 2>(x, packed, y, B, M, K, G, s);
+        default: return launch_fused_mt<7, TW, 2>(x, packed, y, B, M, K, G, s);
     }
 }
 
@@ -516,15 +536,16 @@ GFN_EXPORT int gfn_conv_block_fwd(const float *x, const float *packed, float *y,
     if (x == y) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: in-place is not supported (cells read their neighbours)");
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
-    int nblk, mt;
-    slab_shape(M, &nblk, &mt);
+    if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: C*G*G must fit 31 bits");
     const bool fused = variant != 1 && (G & 3) == 0;
     if (fused) {
         // tile width: full 128-byte rows where the map allows, narrower tiles for the 5*2^k grids
-        if (G % 32 == 0 || G > 160) return launch_fused<32>(mt, x, packed, y, B, M, C, G, nblk, s);
-        if (G % 16 == 0 || G > 64) return launch_fused<16>(mt, x, packed, y, B, M, C, G, nblk, s);
-        return launch_fused<8>(mt, x, packed, y, B, M, C, G, nblk, s);
+        if (G % 32 == 0 || G > 160) return launch_fused<32>(x, packed, y, B, M, C, G, s);
+        if (G % 16 == 0 || G > 64) return launch_fused<16>(x, packed, y, B, M, C, G, s);
+        return launch_fused<8>(x, packed, y, B, M, C, G, s);
     }
+    int nblk, mt;
+    slab_shape(M, &nblk, &mt);
     if (!t_scratch) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: the two-pass variant needs t_scratch (B*C*G*G floats)");
     if ((long)B * C > 0x7fffff || B > 65535) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: batch too large for the two-pass variant");
     const int N = G * G;
