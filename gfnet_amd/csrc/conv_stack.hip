@@ -24,6 +24,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kKT = 16;    // channels per K tile
 constexpr int kNP = 8;     // channel pairs per K tile
@@ -45,7 +47,11 @@ struct PackDims {
     __host__ __device__ size_t cp_off() const { return 0; }
     __host__ __device__ size_t wt_off() const { return (size_t)(Kp / 2) * kCP2; }
     __host__ __device__ size_t bias_off() const { return wt_off() + (size_t)Kp * Mp; }
-    __host__ __device__ size_t total() const { return bias_off() + Mp; }
+    __host__ __device__ size_t wt16_off() const { return bias_off() + Mp; }  // the same weights in fp16 (two per float slot)
+    __host__ __device__ size_t total() const { return wt16_off() + (size_t)Kp * Mp / 2; }
+    // fp16 weights, in halfs from wt16_off: per K tile [k half kg][m][8], k = 16*kt + 8*kg + j: one 16-byte read = a lane's
+    // A operand of v_mfma_f32_32x32x16_f16
+    __host__ __device__ size_t wt16_index(int k, int m) const { return ((size_t)((k >> 4) * 2 + ((k >> 3) & 1)) * Mp + m) * 8 + (k & 7); }
     __host__ __device__ size_t wt_index(int k, int m) const {
         const int kt = k >> 4, r = k & 15, sg = r >> 3, kh = r & 1, j = (r & 7) >> 1;
         return ((size_t)((kt * 2 + sg) * 2 + kh) * Mp + m) * 4 + j;
@@ -74,9 +80,18 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const float *__restrict
             const int j = (int)(e & 3), m = (int)((e >> 2) % d.Mp), g = (int)((e >> 2) / d.Mp);
             const int k = (g >> 2) * 16 + ((g >> 1) & 1) * 8 + 2 * j + (g & 1);
             if (k < C && m < M) v = pw_w[(size_t)m * C + k];
-        } else {
+        } else if (i < d.wt16_off()) {
             const int m = (int)(i - d.bias_off());
             if (m < M) v = pw_b[m];
+        } else {  // invert wt16_index for the two halfs of this slot
+            _Float16 h[2];
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const size_t hidx = 2 * (i - d.wt16_off()) + e2;
+                const int j = (int)(hidx & 7), m = (int)((hidx >> 3) % d.Mp), g = (int)((hidx >> 3) / d.Mp);
+                const int k = (g >> 1) * 16 + (g & 1) * 8 + j;
+                h[e2] = (k < C && m < M) ? (_Float16)pw_w[(size_t)m * C + k] : (_Float16)0.f;
+            }
+            __builtin_memcpy(&v, h, 4);
         }
         packed[i] = v;
     }
@@ -96,29 +111,19 @@ __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2
 
 // ---- fused block ------------------------------------------------------------------------------------
 // Workgroup = NS*4 waves on one 128-cell tile of one map and NS slabs of 32*MT output channels (the
-// waves of both slabs share the depthwise work and the B operand tile).  Steps = K tiles of 16 channels,
-// software pipelined:  global loads run three steps ahead (registers), the LDS commit two (halo Xs, weight
-// tile As[2]), the depthwise arithmetic one (Xs -> B operand tile Bs[2]) ahead of the matrix-core step.
-// Between two barriers a wave does dw(k+1) and mfma(k) -- independent buffers -- and the two halves of
-// the workgroup do them in opposite order, so the SIMD's matrix pipe works for one wave while its
-// partner waits on LDS for the depthwise taps.
-//   halo      channel-pair interleaved [pair][row][cell][2]; cells outside the map are zeroed once
-//             and never written (zero padding for free)
-//   depthwise 2 cells x one channel pair per thread on packed fp32 (v_pk_fma_f32); the pair's taps
-//             are wave-uniform and come from scalar loads
-//   matrix    8 k-steps x MT v_mfma_f32_32x32x2_f32 per wave; B operands (8 x b32) and the A operands
-//             (b128 = four k-steps) are fetched at the top of the step
-template <int MT, int TW, int NS>
+// waves of both slabs share the depthwise work and the B operand tile).  Per K tile of 16 channels:
+//   commit   registers -> LDS: the tile's halo, channel-pair interleaved ([pair][row][cell][2]), the weight
+//            tile W^T[k][m], the pairs' depthwise parameters        | barrier
+//   issue    global loads of the NEXT K tile into registers (land under the arithmetic below)
+//   depthwise  per thread 4/NS cells x one channel pair on packed fp32 (v_pk_fma_f32), relu, into the
+//            B operand tile Bs[pair][cell][2]                        | barrier
+//   matrix   8 k-steps x MT v_mfma_f32_32x32x2_f32 per wave
+// Halo cells outside the map are zeroed once in LDS and never written (zero padding for free).
+template <int MT, int TW, int NS, bool F16>
 __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(const float *__restrict__ x,
                                                                                const float *__restrict__ packed,
                                                                                float *__restrict__ y, int M, int K, int G,
-                                                                               int tiles_x, int tiles_y, int ngrp, unsigned nwork,
-                                                                               int dbg_arg) {
-#ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
-    const int dbg = dbg_arg;
-#else
-    constexpr int dbg = 0;
-#endif
+                                                                               int tiles_x, int tiles_y, int ngrp, unsigned nwork) {
     constexpr int NT = 256 * NS;
     constexpr int TH = kBN / TW;            // tile rows
     constexpr int HR = TH + 4;              // halo rows
@@ -128,24 +133,28 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     constexpr int PS = kNP * HR * RV4;      // staging slots: one = the same 4 cells of both channels of a pair
     constexpr int XPP = (PS + NT - 1) / NT;
     constexpr int BM = 32 * MT, BMS = BM * NS;
-    constexpr int AV4 = 4 * BMS;            // float4 of one weight tile
+    constexpr int GP = F16 ? 2 : 4;         // 16-byte operand groups per weight row and K tile
+    constexpr int AV4 = GP * BMS;           // 16-byte pieces of one weight tile
     constexpr int APT = (AV4 + NT - 1) / NT;
-    constexpr int NPW = kNP / (4 * NS);     // depthwise: channel pairs per wave, one after the other
-    constexpr int GPR = TW / 2;             //            threads per tile row (2 cells each)
+    constexpr int PPT = kNP * kCP2 / NT;    // parameter floats per thread and K tile
+    constexpr int CPT = 4 / NS;             // depthwise: cells per thread
+    constexpr int TPP = kBN / CPT;          //            threads per channel pair
+    constexpr int GPR = TW / CPT;           //            threads per tile row
 
     __shared__ __attribute__((aligned(16))) float Xs[kNP * PP];
-    __shared__ float4 As4[2][4 * BMS];  // [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3
-    __shared__ __attribute__((aligned(16))) float Bs[2][kNP * kBN * 2];  // [buf][pair][cell][2]
+    // fp32: [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3;  fp16: [buf][kg*BMS + m] = 8 halfs k = 8kg ..
+    __shared__ float4 As4[2][GP * BMS];
+    __shared__ __attribute__((aligned(16))) float Bs[kNP * kBN * 2];
+    __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
 
     const PackDims pd(K, M);
     const float *cp = packed + pd.cp_off();
-    const float4 *wt4 = reinterpret_cast<const float4 *>(packed + pd.wt_off());
+    const float *wt = packed + pd.wt_off();
     const float *bias = packed + pd.bias_off();
-    const int Mp = pd.Mp, nk = pd.Kp / kKT;
+    const int Mp = pd.Mp, Kp = pd.Kp;
     const int plane = G * G;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned L = gfn::xcd_remap(blockIdx.x, nwork);
     const int grp = (int)(L % (unsigned)ngrp);
     L /= (unsigned)ngrp;
@@ -175,32 +184,33 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     static_assert(APT <= 4, "weight tile slots");
     float4 xr0[XPP], xr1[XPP];
     float4 ar0, ar1, ar2, ar3;  // named, not an array: the compiler demotes a float4 array here to LDS
-    auto a_load = [&](int kt, int i) {
+    float pr[PPT];
+    const float4 *wt4 = reinterpret_cast<const float4 *>(F16 ? packed + pd.wt16_off() : wt);
+    auto a_load = [&](int k0, int i) {
         const int e = tid + NT * i;
         const int g = e / BMS, m = m0 + e - g * BMS;
         const bool ok = e < AV4 && m < Mp;
-        return wt4[(size_t)(4 * kt + (ok ? g : 0)) * Mp + (ok ? m : 0)];
+        return wt4[(size_t)((k0 >> 4) * GP + (ok ? g : 0)) * Mp + (ok ? m : 0)];
     };
     auto a_store = [&](int buf, int i, const float4 &v) {
         const int e = tid + NT * i;
         if (e < AV4) As4[buf][e] = v;
     };
-    auto issue = [&](int kt) {
-        const int k0 = kt * kKT;
-        if (dbg & 1) return;
+    auto issue = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
             const int c0 = min(k0 + xp2[i], K - 1), c1 = min(k0 + xp2[i] + 1, K - 1);  // past C: any finite data, its taps are 0
             xr0[i] = *reinterpret_cast<const float4 *>(xb + c0 * plane + xg[i]);
             xr1[i] = *reinterpret_cast<const float4 *>(xb + c1 * plane + xg[i]);
         }
-        if constexpr (APT > 0) ar0 = a_load(kt, 0);
-        if constexpr (APT > 1) ar1 = a_load(kt, 1);
-        if constexpr (APT > 2) ar2 = a_load(kt, 2);
-        if constexpr (APT > 3) ar3 = a_load(kt, 3);
+        if constexpr (APT > 0) ar0 = a_load(k0, 0);
+        if constexpr (APT > 1) ar1 = a_load(k0, 1);
+        if constexpr (APT > 2) ar2 = a_load(k0, 2);
+        if constexpr (APT > 3) ar3 = a_load(k0, 3);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
     };
     auto commit = [&](int buf) {
-        if (dbg & 16) return;
 #pragma unroll
         for (int i = 0; i < XPP; ++i)
             if (xv[i]) {
@@ -214,6 +224,8 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 1) a_store(buf, 1, ar1);
         if constexpr (APT > 2) a_store(buf, 2, ar2);
         if constexpr (APT > 3) a_store(buf, 3, ar3);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) Ps[tid + NT * i] = pr[i];
     };
 
     f32x16 acc[MT];
@@ -224,93 +236,98 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
 
     const int col = lane & 31, kh = lane >> 5;
     const int slab = wave >> 2, cw = wave & 3;  // matrix role: output slab, 32-cell group
-    // depthwise role: pairs wave*NPW .. +NPW-1 of the K tile; tile row dr, cells dc, dc+1
-    const int dr = lane / GPR, dc = (lane - dr * GPR) * 2;
-    const int dw_src0 = dr * RPP + 2 * (dc + 2);  // staged cell index = tile cell + 4; taps reach cells dc-2 .. dc+3
-    const int dw_dst0 = (dr * TW + dc) * 2;
+    // depthwise role: channel pair dp, tile row dr, cells dc .. dc+CPT-1
+    const int dp = tid / TPP, dg = tid - dp * TPP, dr = dg / GPR, dc = (dg - dr * GPR) * CPT;
+    const float *dw_src = &Xs[dp * PP + dr * RPP + 2 * (dc + 2)];  // staged cell index = tile cell + 4; taps reach cells dc-2 ..
+    const f32x2 *dw_par = reinterpret_cast<const f32x2 *>(&Ps[dp * kCP2]);
+    float *dw_dst = &Bs[(dp * kBN + dr * TW + dc) * 2];
 
-    // depthwise 5x5 + affine + relu of K tile kt (staged in Xs) into Bs[buf]
-    auto depthwise = [&](int kt, int buf) {
-        if (dbg & 2) return;
+    issue(0);
+    __syncthreads();  // Xs zeroed
+    int buf = 0;
+    for (int k0 = 0; k0 < Kp; k0 += kKT, buf ^= 1) {
+        commit(buf);
+        __syncthreads();
+        if (k0 + kKT < Kp) issue(k0 + kKT);
+        {
+            f32x2 a[CPT];
 #pragma unroll
-        for (int pw = 0; pw < NPW; ++pw) {
-            const int dp = wave * NPW + pw;
-            const f32x2 *par = reinterpret_cast<const f32x2 *>(cp + (size_t)(kt * kNP + dp) * kCP2);  // wave-uniform: scalar loads
-            const float *src = &Xs[dp * PP + dw_src0];
-            f32x2 a0 = f32x2{0.f, 0.f}, a1 = f32x2{0.f, 0.f};
+            for (int j = 0; j < CPT; ++j) a[j] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
-                f32x2 v[6];
+                f32x2 v[CPT + 4];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float4 f = *reinterpret_cast<const float4 *>(src + dy * RPP + 4 * q);
+                for (int q = 0; q < (CPT + 4) / 2; ++q) {
+                    const float4 f = *reinterpret_cast<const float4 *>(dw_src + dy * RPP + 4 * q);
                     v[2 * q] = f32x2{f.x, f.y};
                     v[2 * q + 1] = f32x2{f.z, f.w};
                 }
 #pragma unroll
                 for (int dx = 0; dx < 5; ++dx) {
-                    const f32x2 w = par[dy * 5 + dx];
-                    a0 = pk_fma(w, v[dx], a0);
-                    a1 = pk_fma(w, v[dx + 1], a1);
+                    const f32x2 w = dw_par[dy * 5 + dx];
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) a[j] = pk_fma(w, v[j + dx], a[j]);
                 }
             }
-            const f32x2 t0 = dw_finish2(a0, par[25], par[26], par[27]), t1 = dw_finish2(a1, par[25], par[26], par[27]);
-            *reinterpret_cast<float4 *>(&Bs[buf][dp * kBN * 2 + dw_dst0]) = make_float4(t0.x, t0.y, t1.x, t1.y);
+            const f32x2 cb = dw_par[25], al = dw_par[26], be = dw_par[27];
+            if constexpr (F16) {  // B operand tile in fp16: [k half kg][cell][8], the pair's two channels side by side
+                f16x2 *dst16 = reinterpret_cast<f16x2 *>(Bs) + (((dp >> 2) * kBN + dr * TW + dc) * 4 + (dp & 3));
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const f32x2 t = dw_finish2(a[j], cb, al, be);
+                    dst16[4 * j] = f16x2{(_Float16)t.x, (_Float16)t.y};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    const f32x2 t0 = dw_finish2(a[j], cb, al, be), t1 = dw_finish2(a[j + 1], cb, al, be);
+                    *reinterpret_cast<float4 *>(dw_dst + 2 * j) = make_float4(t0.x, t0.y, t1.x, t1.y);
+                }
+            }
         }
-    };
-    // y += W[:, K tile] . t on the matrix core from As4[buf], Bs[buf]: 2*MT units of four MFMAs (one row
-    // tile, four k-steps, one b128 of A operands); the A operands run two units ahead in a 3-slot ring
-    auto matrix = [&](int buf) {
-        if (dbg & 4) return;
-        const float *bsrc = &Bs[buf][(cw * 32 + col) * 2 + kh];  // t[2s+kh][cell] at + s*256
-        const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
-        auto a_at = [&](int u) { return asrc[(u / MT) * 2 * BMS + (u % MT) * 32]; };
-        float bv[8];
-        float4 av[3];
+        __syncthreads();
+        if constexpr (F16) {  // one v_mfma_f32_32x32x16_f16 per row tile: lane (n or m = lane&31, kg = lane>>5) holds 8 halfs
+            const f16x8 bv = reinterpret_cast<const f16x8 *>(Bs)[kh * kBN + cw * 32 + col];
+            const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][kh * BMS + slab * BM + col]);
+            f16x8 av[MT];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) bv[s8] = bsrc[s8 * 2 * kBN];
-        av[0] = a_at(0);
-        av[1] = a_at(1);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
 #pragma unroll
-        for (int u = 0; u < 2 * MT; ++u) {
-            if (u + 2 < 2 * MT) av[(u + 2) % 3] = a_at(u + 2);
-            const float4 a = av[u % 3];
-            const int i = u % MT, s0 = (u / MT) * 4;
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[s0], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[s0 + 1], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[s0 + 2], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[s0 + 3], acc[i], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv, acc[i], 0, 0, 0);
+        } else {
+            // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
+            // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
+            const float *bsrc = &Bs[(cw * 32 + col) * 2 + kh];  // t[2s+kh][cell] at + s*256
+            const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
+            float bv[8];
+            float4 av[MT];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) bv[s8] = bsrc[s8 * 2 * kBN];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[3], acc[i], 0, 0, 0);
+                av[i] = asrc[2 * BMS + i * 32];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[4], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[5], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[6], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[7], acc[i], 0, 0, 0);
+            }
         }
-    };
-
-    // ---- prologue: step 0 staged and its depthwise done, step 1 staged, step 2 in registers
-    issue(0);
-    __syncthreads();  // Xs zeroed
-    commit(0);
-    __syncthreads();
-    if (nk > 1) issue(1);
-    depthwise(0, 0);
-    __syncthreads();
-    if (nk > 1) commit(1);
-    if (nk > 2) issue(2);
-    // which half of the workgroup (NS = 2) / which workgroup of a CU pair (NS = 1) runs the matrix step first
-    const bool matrix_first = NS == 2 ? wave >= 4 : (blockIdx.x >> 3) & 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        __syncthreads();
-        if (!matrix_first && kt + 1 < nk) depthwise(kt + 1, buf ^ 1);
-        matrix(buf);  // one call site: the accumulators stay in place
-        if (matrix_first && kt + 1 < nk) depthwise(kt + 1, buf ^ 1);
-        __syncthreads();
-        if (kt + 2 < nk) commit(buf);
-        if (kt + 3 < nk) issue(kt + 3);
     }
     // D[row][col]: col = lane&31 -> cell cw*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int p = cw * 32 + col;
     const int gy = row0 + p / TW, gx = col0 + p % TW;
-    if (gy < G && gx < G && !((dbg & 8) && acc[0][0] != 12345.f)) {
+    if (gy < G && gx < G) {
         float *yb = y + (size_t)b * M * plane + (size_t)gy * G + gx;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -392,8 +409,8 @@ __global__ __launch_bounds__(256) void dw5x5_kernel(const float *__restrict__ x,
     for (int q = 0; q < VEC; ++q) dst[q] = dw_finish(acc[q], wc[50], wc[52], wc[54]);
 }
 
-// y[b] = W . t[b] + bias on the fp32 matrix core; same k order as the fused kernel.
-template <int MT>
+// y[b] = W . t[b] + bias on the matrix core; same operands, instruction and k order as the fused kernel.
+template <int MT, bool F16>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const float *__restrict__ packed, const float *__restrict__ t,
                                                          float *__restrict__ y, int M, int K, int N) {
     constexpr int BM = 32 * MT;
@@ -435,13 +452,28 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const float *__restrict
             *reinterpret_cast<float4 *>(&Bs[k][n4 * 4]) = v;
         }
         __syncthreads();
+        if constexpr (F16) {
+            const _Float16 *w16 = reinterpret_cast<const _Float16 *>(packed + pd.wt16_off());
+            f16x8 bv;
 #pragma unroll
-        for (int s = 0; s < kKT / 2; ++s) {
-            const float bv = Bs[2 * s + kh][wave * 32 + col];
+            for (int j = 0; j < 8; ++j) bv[j] = (_Float16)Bs[8 * kh + j][wave * 32 + col];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const float av = As[2 * s + kh][i * 32 + col];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                const int m = m0 + i * 32 + col;
+                f16x8 av;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = m < Mp ? w16[pd.wt16_index(k0 + 8 * kh + j, m)] : (_Float16)0.f;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < kKT / 2; ++s) {
+                const float bv = Bs[2 * s + kh][wave * 32 + col];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float av = As[2 * s + kh][i * 32 + col];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -494,41 +526,41 @@ inline void slab_shape(int M, int *nblk, int *mt) {
     *mt = (tiles + *nblk - 1) / *nblk;
 }
 
-template <int MT, int TW, int NS>
-int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
+template <int MT, int TW, int NS, bool F16>
+int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
     constexpr int TH = kBN / TW;
     const int tiles_x = (G + TW - 1) / TW, tiles_y = (G + TH - 1) / TH;
     const int ngrp = (M + 32 * MT * NS - 1) / (32 * MT * NS);
     const long nwork = (long)B * tiles_x * tiles_y * ngrp;
     if (nwork > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: too many tiles");
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
-                       tiles_y, ngrp, (unsigned)nwork, dbg);
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
+                       tiles_y, ngrp, (unsigned)nwork);
     return gfn::check_launch("dwpw_fused_kernel");
 }
 
 // output channels: one workgroup computes all of them where they fit 2 slabs of <= 7 MFMA row tiles
 // (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once
-template <int TW>
-int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
+template <int TW, bool F16>
+int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
     const int tiles = (M + 31) / 32;
     if (tiles <= 7) {
         switch (tiles) {
-            case 1: return launch_fused_mt<1, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            case 2: return launch_fused_mt<2, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            case 3: return launch_fused_mt<3, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            case 4: return launch_fused_mt<4, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            case 5: return launch_fused_mt<5, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            case 6: return launch_fused_mt<6, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
-            default: return launch_fused_mt<7, TW, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 1: return launch_fused_mt<1, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 2: return launch_fused_mt<2, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 3: return launch_fused_mt<3, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 4: return launch_fused_mt<4, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 5: return launch_fused_mt<5, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 6: return launch_fused_mt<6, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            default: return launch_fused_mt<7, TW, 1, F16>(x, packed, y, B, M, K, G, s);
         }
     }
     const int ngrp = (tiles + 13) / 14;
     const int mt = ((tiles + ngrp - 1) / ngrp + 1) / 2;  // row tiles per slab
     switch (mt) {
-        case 4: return launch_fused_mt<4, TW, 2>(x, packed, y, B, M, K, G, dbg, s);
-        case 5: return launch_fused_mt<5, TW, 2>(x, packed, y, B, M, K, G, dbg, s);
-        case 6: return launch_fused_mt<6, TW, 2>(x, packed, y, B, M, K, G, dbg, s);
-        default: return launch_fused_mt<7, TW, 2>(x, packed, y, B, M, K, G, dbg, s);
+        case 4: return launch_fused_mt<4, TW, 2, F16>(x, packed, y, B, M, K, G, s);
+        case 5: return launch_fused_mt<5, TW, 2, F16>(x, packed, y, B, M, K, G, s);
+        case 6: return launch_fused_mt<6, TW, 2, F16>(x, packed, y, B, M, K, G, s);
+        default: return launch_fused_mt<7, TW, 2, F16>(x, packed, y, B, M, K, G, s);
     }
 }
 
@@ -555,14 +587,16 @@ GFN_EXPORT int gfn_conv_block_fwd(const float *x, const float *packed, float *y,
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
     if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: C*G*G must fit 31 bits");
-    const int dbg = variant >> 8;  // ablation mask, honoured by -DGFN_ABLATE builds only
-    variant &= 0xff;
-    const bool fused = variant != 1 && (G & 3) == 0;
+    if (variant < 0 || variant > 3) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: variant must be 0..3 (got %d)", variant);
+    const bool f16 = (variant & 2) != 0;
+    const bool fused = !(variant & 1) && (G & 3) == 0;
     if (fused) {
         // tile width: full 128-byte rows where the map allows, narrower tiles for the 5*2^k grids
-        if (G % 32 == 0 || G > 160) return launch_fused<32>(x, packed, y, B, M, C, G, dbg, s);
-        if (G % 16 == 0 || G > 64) return launch_fused<16>(x, packed, y, B, M, C, G, dbg, s);
-        return launch_fused<8>(x, packed, y, B, M, C, G, dbg, s);
+        if (G % 32 == 0 || G > 160)
+            return f16 ? launch_fused<32, true>(x, packed, y, B, M, C, G, s) : launch_fused<32, false>(x, packed, y, B, M, C, G, s);
+        if (G % 16 == 0 || G > 64)
+            return f16 ? launch_fused<16, true>(x, packed, y, B, M, C, G, s) : launch_fused<16, false>(x, packed, y, B, M, C, G, s);
+        return f16 ? launch_fused<8, true>(x, packed, y, B, M, C, G, s) : launch_fused<8, false>(x, packed, y, B, M, C, G, s);
     }
     int nblk, mt;
     slab_shape(M, &nblk, &mt);
@@ -578,7 +612,11 @@ GFN_EXPORT int gfn_conv_block_fwd(const float *x, const float *packed, float *y,
     }
     if (int rc = gfn::check_launch("dw5x5_kernel")) return rc;
     const dim3 grid((N + kBN - 1) / kBN, nblk, B), block(256);
-#define GFN_PW(MT) hipLaunchKernelGGL((pw_gemm_kernel<MT>), grid, block, 0, s, packed, (const float *)t_scratch, y, M, C, N)
+#define GFN_PW(MT)                                                                                                        \
+    if (f16)                                                                                                              \
+        hipLaunchKernelGGL((pw_gemm_kernel<MT, true>), grid, block, 0, s, packed, (const float *)t_scratch, y, M, C, N);  \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((pw_gemm_kernel<MT, false>), grid, block, 0, s, packed, (const float *)t_scratch, y, M, C, N)
     switch (mt) {
         case 1: GFN_PW(1); break;
         case 2: GFN_PW(2); break;

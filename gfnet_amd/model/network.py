@@ -69,6 +69,9 @@ class ConvRefiner(nn.Module):
         # "hip": eval-mode conv stack on csrc/conv_stack.hip (fp32, BatchNorm folded); "torch": nn modules
         # under autocast as in the reference (always used in training mode)
         self.conv_impl = "hip"
+        # 1x1 conv operands on the HIP path: "fp32" (exact fp32 products, the CPU reference's class) or "fp16"
+        # (operands rounded to fp16, fp32 accumulation: the autocast class the reference runs these refiners in on GPU)
+        self.conv_precision = "fp32"
 
     def assemble(self, num_grid, x, y, flow, scale_factor=1):
         """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view."""
@@ -112,10 +115,14 @@ class ConvRefiner(nn.Module):
         self._fold_key, self._fold = key, (fold, out)
         return self._fold
 
-    def conv_stack(self, d, variant=0):
+    def conv_stack(self, d, variant=None):
         """out_conv(hidden_blocks(block1(d))), network.py:560-563, on csrc/conv_stack.hip: one fused
         kernel per block, two ping-pong maps."""
         fold, (ow, ob) = self.folded_stack()
+        if variant is None:
+            if self.conv_precision not in ("fp32", "fp16"):
+                raise ValueError("conv_precision must be 'fp32' or 'fp16'")
+            variant = 2 if self.conv_precision == "fp16" else 0
         x, bufs = d, [None, None]
         for i, (packed, M) in enumerate(fold):
             if bufs[i & 1] is None or bufs[i & 1].shape[1] != M:

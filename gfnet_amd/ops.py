@@ -308,7 +308,9 @@ def conv_block_pack(dw_w, dw_b, bn_alpha, bn_beta, pw_w, pw_b):
 
 def conv_block(x, packed, M, out=None, variant=0, t_scratch=None):
     """Conv2d(C,C,5,pad 2,groups=C) -> BatchNorm2d(eval) -> ReLU -> Conv2d(C,M,1) in one kernel
-    (model/network.py:471-487).  variant=1 forces the two-pass form (bit-identical)."""
+    (model/network.py:471-487).  variant bit 0: the two-pass form (bit-identical to the fused one);
+    bit 1: 1x1 conv with fp16 operands (W and the ReLU output rounded to fp16, fp32 accumulation) --
+    the reference's autocast numerics class (amp=True refiners) -- instead of fp32 throughout."""
     dev = require_gpu(x, packed)
     x = f32c(x)
     B, C, G, G2 = x.shape
@@ -318,7 +320,7 @@ def conv_block(x, packed, M, out=None, variant=0, t_scratch=None):
         raise ValueError("conv_block: packed parameters do not match (C=%d, M=%d)" % (C, M))
     if out is None:
         out = torch.empty((B, M, G, G), device=dev, dtype=torch.float32)
-    if (variant == 1 or G % 4) and t_scratch is None:
+    if ((variant & 1) or G % 4) and t_scratch is None:
         t_scratch = torch.empty_like(x)
     check(_timed("conv_block_c%d_g%d" % (C, G), lambda: _L().gfn_conv_block_fwd(
         ptr(x), ptr(packed), ptr(out), ptr(t_scratch) if t_scratch is not None else None, B, C, M, G, int(variant),

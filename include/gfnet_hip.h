@@ -196,16 +196,20 @@ int gfn_homography_dlt(const float *pts, const float *weight, int Bt, int N, dou
 /* ---------------------------------------------------------------------------------------------
  * Refiner conv stack -- ConvRefiner.create_block / forward, model/network.py:471-487
  * and :560-563: nine blocks of depthwise 5x5 conv -> BatchNorm2d(eval) -> ReLU -> 1x1 conv, then a
- * final 1x1 conv to 3 channels.  fp32 throughout (fp32 matrix-core products and accumulation).
+ * final 1x1 conv to 3 channels.  Depthwise, norm and accumulation always fp32; the 1x1 products fp32
+ * (default) or fp16.
  *
  * gfn_conv_block_pack: lays one block's parameters out for the kernels (device to device):
  *   dw_w (C,25) depthwise taps, dw_b (C) or NULL, bn_alpha/bn_beta (C) the eval-mode BatchNorm as
  *   y = x*alpha + beta (alpha = weight/sqrt(running_var+eps), beta = bias - running_mean*alpha),
  *   pw_w (M,C) and pw_b (M) the 1x1 conv; packed: gfn_conv_block_packed_floats(C, M) floats.
  * gfn_conv_block_fwd: y = pw(relu(bn(dw(x)))) for x (B,C,G,G) -> y (B,M,G,G), zero padding 2; y must
- *   not alias x.  variant 0: one fused kernel when G % 4 == 0, otherwise the two-pass form;
- *   variant 1: always two-pass (depthwise kernel -> t_scratch (B*C*G*G floats) -> GEMM kernel);
- *   both give bit-identical results.  t_scratch may be NULL when the fused kernel applies.
+ *   not alias x.  variant bit 0 (1): two-pass form (depthwise kernel -> t_scratch (B*C*G*G floats) ->
+ *   GEMM kernel) instead of the fused kernel; also taken when G % 4 != 0; bit-identical results.
+ *   variant bit 1 (2): the 1x1 conv takes fp16 operands (W and relu output rounded to nearest fp16,
+ *   v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the reference's autocast numerics class for its
+ *   amp=True refiners (model/network.py:560-562) -- instead of fp32 throughout.  t_scratch may be NULL
+ *   when the fused kernel applies.
  * gfn_pointwise_conv_fwd: y[b] = W . t[b] + bias for a few output channels (M <= 16; the final C -> 3
  *   conv, network.py:505,563): w (M,K), t (B,K,N), y (B,M,N).
  */

@@ -53,6 +53,25 @@ def test_conv_block_matches_torch_float64(B, C, M, G):
     assert torch.equal(got, two_pass), "fused and two-pass kernels must agree bit for bit"
 
 
+@pytest.mark.parametrize("B,C,M,G", CASES)
+def test_conv_block_fp16_operands(B, C, M, G):
+    """variant 2: W and relu output rounded to fp16, fp32 accumulation.  Checked against float64 math on
+    the same rounded operands (tight) and against the unrounded result (fp16 operand error bound)."""
+    from gfnet_amd import ops
+
+    x, (w, cb, alpha, beta, pw, pb), want = _block_case(B, C, M, G, bias=(C % 2 == 1))
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    got = ops.conv_block(x, packed, M, variant=2)
+    assert torch.equal(got, ops.conv_block(x, packed, M, variant=3)), "fused and two-pass fp16 kernels must agree bit for bit"
+    t = F.relu((F.conv2d(x.double(), w.double(), cb.double() if cb is not None else None, padding=2, groups=C)
+                * alpha.double().view(1, C, 1, 1) + beta.double().view(1, C, 1, 1)))
+    rounded = F.conv2d(t.float().half().double(), pw.half().double().reshape(M, C, 1, 1), pb.double())
+    err, mag = _maxerr(got, rounded)
+    assert err <= 1e-3 * max(mag, 1.0), (err, mag)  # a few relu outputs round the other way (fp32 vs float64 depthwise)
+    err, mag = _maxerr(got, want)
+    assert err <= 4e-3 * max(mag, 1.0), (err, mag)
+
+
 @pytest.mark.parametrize("B,M,K,G", [(3, 3, 24, 16), (2, 3, 417, 8), (1, 5, 7, 5), (1, 1, 3, 4)])
 def test_pointwise_conv_matches_torch(B, M, K, G):
     from gfnet_amd import ops
@@ -78,6 +97,8 @@ def test_conv_block_rejects_bad_arguments():
         ops.conv_block(x, packed, 40)  # packed for another shape
     with pytest.raises(GfnError):
         ops.pointwise_conv(x, _rand(17, 8), _rand(17))  # too many outputs for the small-M kernel
+    with pytest.raises(GfnError):
+        ops.conv_block(x, packed, 8, variant=4)
 
 
 @pytest.mark.parametrize("feat,disp,r,G,B", [(8, 8, 0, 64, 3), (16, 16, 2, 32, 2), (32, 32, 4, 16, 2), (64, 64, 7, 8, 1),
@@ -103,9 +124,19 @@ def test_conv_stack_matches_torch_modules(feat, disp, r, G, B):
         want = ref.out_conv(ref.hidden_blocks(ref.block1(d.clone())))
         got = ref.conv_stack(d)
         got2 = ref.conv_stack(d, variant=1)
+        ref.conv_precision = "fp16"
+        got16 = ref.conv_stack(d)
+        ref.conv_precision = "fp32"
+        with torch.autocast("cuda", dtype=torch.float16):
+            want16 = ref.out_conv(ref.hidden_blocks(ref.block1(d.clone())).float())
     err, mag = _maxerr(got, want)
     assert err <= 1e-4 * max(mag, 1.0), (err, mag)
     assert torch.equal(got, got2)
+    # fp16 operands: closer to the fp32 result than torch's own fp16 autocast of the same modules is
+    err16, _ = _maxerr(got16, want)
+    err_amp, _ = _maxerr(want16, want)
+    assert err16 <= 2e-2 * max(mag, 1.0), (err16, mag)
+    assert err16 <= 2.0 * err_amp + 1e-6, (err16, err_amp)
     # a changed running statistic invalidates the folded parameters
     with torch.no_grad():
         ref.block1[1].running_mean.add_(0.5)

@@ -21,7 +21,7 @@ def timeit(fn, n=3):
     return e0.elapsed_time(e1) / n
 
 
-for variant in (0, 1):
+for variant in [int(v) for v in os.environ.get("PROBE_VARIANTS", "0,2").split(",")]:
     total = 0.0
     for name, shapes in (("448", shapes448), ("560", shapes560)):
         for (s, feat, disp, r, G) in shapes:
