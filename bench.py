@@ -92,14 +92,23 @@ class StandInRefiner(nn.Module):
     the increment that moves the flow onto the true warp (smooth, also outside the overlap) and a
     constant certainty increment.  Two tiny torch elementwise ops; everything else is the real path."""
 
-    def __init__(self, feat, disp, radius, scale, gt):
+    def __init__(self, feat, disp, radius, scale, gt, conv_stack="off"):
         super().__init__()
-        from gfnet_amd.model.network import ConvRefiner
+        from gfnet_amd.model.network import ConvRefiner, _refiner_for
 
         K = (2 * radius + 1) ** 2 if radius > 0 else 0
         dim = 2 * feat + disp + K
-        self.inner = ConvRefiner(dim, dim, 3, kernel_size=5, dw=True, hidden_blocks=0, displacement_emb="linear",
-                                 displacement_emb_dim=disp, local_corr_num=radius, corr_in_other=radius > 0)
+        if conv_stack == "off":
+            self.inner = ConvRefiner(dim, dim, 3, kernel_size=5, dw=True, hidden_blocks=0, displacement_emb="linear",
+                                     displacement_emb_dim=disp, local_corr_num=radius, corr_in_other=radius > 0)
+        else:
+            # --conv-stack: the reference's refiner architecture for this scale (9 depthwise+1x1 blocks and the
+            # output conv, random-init, eval) runs on the HIP conv-stack kernels (SURVEY 8(f) N1).  Random weights
+            # cannot refine anything, so its output enters with weight 0 and the stand-in increment below keeps the
+            # synthetic scene consistent; all of its arithmetic is executed inside the timed region.
+            self.inner = _refiner_for(feat, disp, radius)
+            self.inner.conv_precision = conv_stack
+        self.conv_stack = conv_stack
         self.scale, self.gt = scale, gt  # gt: {num_grid: (true flow (2B,2,G,G), image size)}
         self._cert = {}
 
@@ -109,7 +118,12 @@ class StandInRefiner(nn.Module):
         delta = (gt - flow) * (4.0 * size / self.scale)   # undone by network.py:262-263's scale/(4*W0)
         if num_grid not in self._cert:
             self._cert[num_grid] = torch.full((flow.shape[0], 1, num_grid, num_grid), 1.0, device=flow.device)
-        return delta, self._cert[num_grid], lc
+        cert = self._cert[num_grid]
+        if self.conv_stack != "off":
+            out = self.inner.conv_stack(d)
+            delta = torch.addcmul(delta, out[:, :2], torch.zeros((), device=d.device))
+            cert = torch.addcmul(cert, out[:, 2:3], torch.zeros((), device=d.device))
+        return delta, cert, lc
 
 
 def algorithmic_bytes_local_corr(B, c, hs, G, r):
@@ -173,6 +187,9 @@ def main():
     ap.add_argument("--no-upsample", action="store_true", help="448 pass only (no 560 refinement pass)")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs for the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="print per-stage GPU times of one step to stderr")
+    ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16"), default="off",
+                    help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP kernels, with "
+                         "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
     args = ap.parse_args()
 
     from gfnet_amd import ops, parallel
@@ -205,7 +222,7 @@ def main():
     if upsample:
         for G in (40, 80, 160, 320):
             gt[G] = (torch.cat((warp_grid(Hup, G, S1, dev), warp_grid(Hupinv, G, S1, dev))).permute(0, 3, 1, 2).contiguous(), S1)
-    refiners = nn.ModuleDict({s: StandInRefiner(FEAT[s], DISP[s], CONF["matcher"]["radius"][i], int(s), gt)
+    refiners = nn.ModuleDict({s: StandInRefiner(FEAT[s], DISP[s], CONF["matcher"]["radius"][i], int(s), gt, args.conv_stack)
                               for i, s in enumerate(scales)})
     model = GFNet(CONF, symmetric=True, upsample_preds=upsample, attenuate_cert=True, conv_refiner=refiners).to(dev).eval()
     sizes = (S0, S0, S0, S0)
@@ -269,8 +286,12 @@ def main():
                    "pairs_per_gpu": B, "symmetric": True, "upsample_pass_560": upsample, "attenuate_cert": True,
                    "stages": "corr_softargmax, refiner_input+local_corr x(4+3 scales), flow_update, resize, match_post, "
                              "sample(multinomial+KDE 20000^2), RANSAC(2000)+DLT+LM, H all-gather",
-                   "excluded": "DINOv2/FPN backbone and refiner conv stacks (PyTorch-ROCm host code); stand-in increment = "
-                               "exact residual to the true warp (2 torch elementwise ops per refiner call)",
+                   "excluded": ("DINOv2/FPN backbone and refiner conv stacks (PyTorch-ROCm host code); stand-in increment = "
+                                "exact residual to the true warp (2 torch elementwise ops per refiner call)") if args.conv_stack == "off"
+                   else "DINOv2/FPN backbone (PyTorch-ROCm host code)",
+                   "refiner_conv_stack": "off" if args.conv_stack == "off" else
+                   f"reference architecture (9 dw5x5+BN+ReLU+1x1 blocks + out conv per refiner call, C=417/361/177/73/24), random-init, "
+                   f"HIP conv_stack kernels, 1x1 operands {args.conv_stack}; output weighted 0 next to the stand-in increment",
                    "parallelism": f"pairs sharded over {world} GPU(s), RCCL all-gather of H only"},
         "roofline": {"bound": "hbm", "kernel": "gfn_local_corr_fwd call = local_corr_tile_kernel<4,2> + local_corr_irregular_kernel<4,2> "
                                                "(c32, 112x112, G64, r4, 64 directions)",
