@@ -119,13 +119,21 @@ __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2
 //            B operand tile Bs[pair][cell][2]                        | barrier
 //   matrix   8 k-steps x MT v_mfma_f32_32x32x2_f32 per wave
 // Halo cells outside the map are zeroed once in LDS and never written (zero padding for free).
-template <int MT, int TW, int NS, bool F16>
+template <int MT, int TW, int NS, bool F16, int NB>
 __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(const float *__restrict__ x,
                                                                                const float *__restrict__ packed,
                                                                                float *__restrict__ y, int M, int K, int G,
-                                                                               int tiles_x, int tiles_y, int ngrp, unsigned nwork) {
+                                                                               int tiles_x, int tiles_y, int ngrp, unsigned nwork,
+                                                                               int dbg_arg) {
+#ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+#endif
+    static_assert(NB == 1 || (NB == 2 && NS == 1 && MT <= 3), "256-cell tiles: one slab of at most 96 output channels");
     constexpr int NT = 256 * NS;
-    constexpr int TH = kBN / TW;            // tile rows
+    constexpr int BN = kBN * NB;            // cells per workgroup tile
+    constexpr int TH = BN / TW;             // tile rows
     constexpr int HR = TH + 4;              // halo rows
     constexpr int RV4 = (TW + 8) / 4;       // float4 per staged halo row and channel: cells col0-4 .. col0+TW+3
     constexpr int RPP = (TW + 8) * 2 + 4;   // LDS floats per halo row of a channel pair (+4: bank spread)
@@ -137,14 +145,15 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     constexpr int AV4 = GP * BMS;           // 16-byte pieces of one weight tile
     constexpr int APT = (AV4 + NT - 1) / NT;
     constexpr int PPT = kNP * kCP2 / NT;    // parameter floats per thread and K tile
-    constexpr int CPT = 4 / NS;             // depthwise: cells per thread
+    constexpr int CPT = 4 / NS;             // depthwise: cells per thread and row
+    constexpr int RB = NB;                  //            rows per thread
     constexpr int TPP = kBN / CPT;          //            threads per channel pair
     constexpr int GPR = TW / CPT;           //            threads per tile row
 
     __shared__ __attribute__((aligned(16))) float Xs[kNP * PP];
     // fp32: [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3;  fp16: [buf][kg*BMS + m] = 8 halfs k = 8kg ..
     __shared__ float4 As4[2][GP * BMS];
-    __shared__ __attribute__((aligned(16))) float Bs[kNP * kBN * 2];
+    __shared__ __attribute__((aligned(16))) float Bs[F16 ? BN * 8 : kNP * BN * 2];  // fp32 [pair][cell][2] / fp16 [k half][cell][8]
     __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
 
     const PackDims pd(K, M);
@@ -179,7 +188,8 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         xp2[i] = 2 * p;
         xl[i] = p * PP + hr * RPP + 8 * q;
     }
-    for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(dbg & 32))
+        for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     static_assert(APT <= 4, "weight tile slots");
     float4 xr0[XPP], xr1[XPP];
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if (e < AV4) As4[buf][e] = v;
     };
     auto issue = [&](int k0) {
+        if (dbg & 1) return;
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
             const int c0 = min(k0 + xp2[i], K - 1), c1 = min(k0 + xp2[i] + 1, K - 1);  // past C: any finite data, its taps are 0
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
     };
     auto commit = [&](int buf) {
+        if (dbg & 16) return;
 #pragma unroll
         for (int i = 0; i < XPP; ++i)
             if (xv[i]) {
@@ -228,19 +240,19 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         for (int i = 0; i < PPT; ++i) Ps[tid + NT * i] = pr[i];
     };
 
-    f32x16 acc[MT];
+    f32x16 acc[NB * MT];  // [cell half g][row tile i]
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < NB * MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int col = lane & 31, kh = lane >> 5;
-    const int slab = wave >> 2, cw = wave & 3;  // matrix role: output slab, 32-cell group
-    // depthwise role: channel pair dp, tile row dr, cells dc .. dc+CPT-1
-    const int dp = tid / TPP, dg = tid - dp * TPP, dr = dg / GPR, dc = (dg - dr * GPR) * CPT;
+    const int slab = wave >> 2, cw = wave & 3;  // matrix role: output slab, 32-cell group (of each 128-cell half)
+    // depthwise role: channel pair dp, tile rows dr .. dr+RB-1, cells dc .. dc+CPT-1
+    const int dp = tid / TPP, dg = tid - dp * TPP, dr = (dg / GPR) * RB, dc = (dg - (dg / GPR) * GPR) * CPT;
     const float *dw_src = &Xs[dp * PP + dr * RPP + 2 * (dc + 2)];  // staged cell index = tile cell + 4; taps reach cells dc-2 ..
     const f32x2 *dw_par = reinterpret_cast<const f32x2 *>(&Ps[dp * kCP2]);
-    float *dw_dst = &Bs[(dp * kBN + dr * TW + dc) * 2];
+    float *dw_dst = &Bs[F16 ? 0 : (dp * BN + dr * TW + dc) * 2];
 
     issue(0);
     __syncthreads();  // Xs zeroed
@@ -249,85 +261,107 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         commit(buf);
         __syncthreads();
         if (k0 + kKT < Kp) issue(k0 + kKT);
-        {
-            f32x2 a[CPT];
+        if (!(dbg & 2)) {  // depthwise: RB output rows x CPT cells x one channel pair; every halo row and every tap row is read once
+            f32x2 a[RB][CPT];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) a[j] = f32x2{0.f, 0.f};
+            for (int ro = 0; ro < RB; ++ro)
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy) {
+                for (int j = 0; j < CPT; ++j) a[ro][j] = f32x2{0.f, 0.f};
+            f32x2 w[2][5];  // tap rows hy and hy-1
+#pragma unroll
+            for (int hy = 0; hy < 4 + RB; ++hy) {
                 f32x2 v[CPT + 4];
 #pragma unroll
                 for (int q = 0; q < (CPT + 4) / 2; ++q) {
-                    const float4 f = *reinterpret_cast<const float4 *>(dw_src + dy * RPP + 4 * q);
+                    const float4 f = *reinterpret_cast<const float4 *>(dw_src + hy * RPP + 4 * q);
                     v[2 * q] = f32x2{f.x, f.y};
                     v[2 * q + 1] = f32x2{f.z, f.w};
                 }
+                if (hy < 5) {
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx) {
-                    const f32x2 w = dw_par[dy * 5 + dx];
+                    for (int dx = 0; dx < 5; ++dx) w[hy & 1][dx] = dw_par[hy * 5 + dx];
+                }
 #pragma unroll
-                    for (int j = 0; j < CPT; ++j) a[j] = pk_fma(w, v[j + dx], a[j]);
+                for (int ro = 0; ro < RB; ++ro) {
+                    const int dy = hy - ro;  // tap row that maps halo row hy onto output row ro
+                    if (dy < 0 || dy > 4) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+                        for (int j = 0; j < CPT; ++j) a[ro][j] = pk_fma(w[dy & 1][dx], v[j + dx], a[ro][j]);
                 }
             }
             const f32x2 cb = dw_par[25], al = dw_par[26], be = dw_par[27];
-            if constexpr (F16) {  // B operand tile in fp16: [k half kg][cell][8], the pair's two channels side by side
-                f16x2 *dst16 = reinterpret_cast<f16x2 *>(Bs) + (((dp >> 2) * kBN + dr * TW + dc) * 4 + (dp & 3));
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) {
-                    const f32x2 t = dw_finish2(a[j], cb, al, be);
-                    dst16[4 * j] = f16x2{(_Float16)t.x, (_Float16)t.y};
-                }
-            } else {
+            for (int ro = 0; ro < RB; ++ro) {
+                if constexpr (F16) {  // B operand tile in fp16: [k half kg][cell][8], the pair's two channels side by side
+                    f16x2 *dst16 = reinterpret_cast<f16x2 *>(Bs) + (((dp >> 2) * BN + (dr + ro) * TW + dc) * 4 + (dp & 3));
 #pragma unroll
-                for (int j = 0; j < CPT; j += 2) {
-                    const f32x2 t0 = dw_finish2(a[j], cb, al, be), t1 = dw_finish2(a[j + 1], cb, al, be);
-                    *reinterpret_cast<float4 *>(dw_dst + 2 * j) = make_float4(t0.x, t0.y, t1.x, t1.y);
+                    for (int j = 0; j < CPT; ++j) {
+                        const f32x2 t = dw_finish2(a[ro][j], cb, al, be);
+                        dst16[4 * j] = f16x2{(_Float16)t.x, (_Float16)t.y};
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPT; j += 2) {
+                        const f32x2 t0 = dw_finish2(a[ro][j], cb, al, be), t1 = dw_finish2(a[ro][j + 1], cb, al, be);
+                        *reinterpret_cast<float4 *>(dw_dst + 2 * (ro * TW + j)) = make_float4(t0.x, t0.y, t1.x, t1.y);
+                    }
                 }
             }
         }
         __syncthreads();
-        if constexpr (F16) {  // one v_mfma_f32_32x32x16_f16 per row tile: lane (n or m = lane&31, kg = lane>>5) holds 8 halfs
-            const f16x8 bv = reinterpret_cast<const f16x8 *>(Bs)[kh * kBN + cw * 32 + col];
-            const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][kh * BMS + slab * BM + col]);
-            f16x8 av[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
+        for (int g = 0; g < NB; ++g) {
+            if (dbg & 4) break;
+            const int cell = (g * 4 + cw) * 32 + col;  // this lane's B column
+            if constexpr (F16) {  // one v_mfma_f32_32x32x16_f16 per row tile: lane (n or m = lane&31, kg = lane>>5) holds 8 halfs
+                const f16x8 bv = reinterpret_cast<const f16x8 *>(Bs)[kh * BN + cell];
+                const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][kh * BMS + slab * BM + col]);
+                f16x8 av[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv, acc[i], 0, 0, 0);
-        } else {
-            // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
-            // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
-            const float *bsrc = &Bs[(cw * 32 + col) * 2 + kh];  // t[2s+kh][cell] at + s*256
-            const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
-            float bv[8];
-            float4 av[MT];
+                for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) bv[s8] = bsrc[s8 * 2 * kBN];
+                for (int i = 0; i < MT; ++i) acc[g * MT + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv, acc[g * MT + i], 0, 0, 0);
+            } else {
+                // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
+                // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
+                const float *bsrc = &Bs[cell * 2 + kh];  // t[2s+kh][cell] at + s*2*BN
+                const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
+                float bv[8];
+                float4 av[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int s8 = 0; s8 < 8; ++s8) bv[s8] = bsrc[s8 * 2 * BN];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[2], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[3], acc[i], 0, 0, 0);
-                av[i] = asrc[2 * BMS + i * 32];
+                for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
                 __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[4], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[5], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[6], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[7], acc[i], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) {
+                    f32x16 &c = acc[g * MT + i];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[3], c, 0, 0, 0);
+                    av[i] = asrc[2 * BMS + i * 32];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    f32x16 &c = acc[g * MT + i];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[4], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[5], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[6], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[7], c, 0, 0, 0);
+                }
             }
         }
     }
-    // D[row][col]: col = lane&31 -> cell cw*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int p = cw * 32 + col;
-    const int gy = row0 + p / TW, gx = col0 + p % TW;
-    if (gy < G && gx < G) {
+    // D[row][col]: col = lane&31 -> cell (g*4+cw)*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int p = (g * 4 + cw) * 32 + col;
+        const int gy = row0 + p / TW, gx = col0 + p % TW;
+        if (gy >= G || gx >= G || ((dbg & 8) && acc[0][0] != 12345.f)) continue;
         float *yb = y + (size_t)b * M * plane + (size_t)gy * G + gx;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -340,19 +374,19 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             if (mb + 32 <= M) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    yt[(size_t)(8 * q) * plane] = acc[i][4 * q] + bq[q].x;
-                    yt[(size_t)(8 * q + 1) * plane] = acc[i][4 * q + 1] + bq[q].y;
-                    yt[(size_t)(8 * q + 2) * plane] = acc[i][4 * q + 2] + bq[q].z;
-                    yt[(size_t)(8 * q + 3) * plane] = acc[i][4 * q + 3] + bq[q].w;
+                    yt[(size_t)(8 * q) * plane] = acc[g * MT + i][4 * q] + bq[q].x;
+                    yt[(size_t)(8 * q + 1) * plane] = acc[g * MT + i][4 * q + 1] + bq[q].y;
+                    yt[(size_t)(8 * q + 2) * plane] = acc[g * MT + i][4 * q + 2] + bq[q].z;
+                    yt[(size_t)(8 * q + 3) * plane] = acc[g * MT + i][4 * q + 3] + bq[q].w;
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mb + 8 * q + 4 * kh;
-                    if (m < M) yt[(size_t)(8 * q) * plane] = acc[i][4 * q] + bq[q].x;
-                    if (m + 1 < M) yt[(size_t)(8 * q + 1) * plane] = acc[i][4 * q + 1] + bq[q].y;
-                    if (m + 2 < M) yt[(size_t)(8 * q + 2) * plane] = acc[i][4 * q + 2] + bq[q].z;
-                    if (m + 3 < M) yt[(size_t)(8 * q + 3) * plane] = acc[i][4 * q + 3] + bq[q].w;
+                    if (m < M) yt[(size_t)(8 * q) * plane] = acc[g * MT + i][4 * q] + bq[q].x;
+                    if (m + 1 < M) yt[(size_t)(8 * q + 1) * plane] = acc[g * MT + i][4 * q + 1] + bq[q].y;
+                    if (m + 2 < M) yt[(size_t)(8 * q + 2) * plane] = acc[g * MT + i][4 * q + 2] + bq[q].z;
+                    if (m + 3 < M) yt[(size_t)(8 * q + 3) * plane] = acc[g * MT + i][4 * q + 3] + bq[q].w;
                 }
             }
         }
@@ -526,41 +560,52 @@ inline void slab_shape(int M, int *nblk, int *mt) {
     *mt = (tiles + *nblk - 1) / *nblk;
 }
 
-template <int MT, int TW, int NS, bool F16>
-int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
-    constexpr int TH = kBN / TW;
+template <int MT, int TW, int NS, bool F16, int NB>
+int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
+    constexpr int TH = kBN * NB / TW;
     const int tiles_x = (G + TW - 1) / TW, tiles_y = (G + TH - 1) / TH;
     const int ngrp = (M + 32 * MT * NS - 1) / (32 * MT * NS);
     const long nwork = (long)B * tiles_x * tiles_y * ngrp;
     if (nwork > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: too many tiles");
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
-                       tiles_y, ngrp, (unsigned)nwork);
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G,
+                       tiles_x, tiles_y, ngrp, (unsigned)nwork, dbg);
     return gfn::check_launch("dwpw_fused_kernel");
 }
 
 // output channels: one workgroup computes all of them where they fit 2 slabs of <= 7 MFMA row tiles
-// (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once
+// (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once.  Narrow blocks
+// (M <= 96: the fine scales, bound by LDS and HBM traffic rather than the matrix core) take 256-cell
+// tiles with two output rows per depthwise thread when the map divides into them.
 template <int TW, bool F16>
-int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, hipStream_t s) {
+int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     const int tiles = (M + 31) / 32;
+    if (F16 && tiles <= 3 && TW >= 16 && G % (2 * kBN / TW) == 0) {  // fp32: the larger tiles cost a resident workgroup (LDS)
+        if constexpr (F16 && TW >= 16) {
+            switch (tiles) {
+                case 1: return launch_fused_mt<1, TW, 1, F16, 2>(x, packed, y, B, M, K, G, dbg, s);
+                case 2: return launch_fused_mt<2, TW, 1, F16, 2>(x, packed, y, B, M, K, G, dbg, s);
+                default: return launch_fused_mt<3, TW, 1, F16, 2>(x, packed, y, B, M, K, G, dbg, s);
+            }
+        }
+    }
     if (tiles <= 7) {
         switch (tiles) {
-            case 1: return launch_fused_mt<1, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            case 2: return launch_fused_mt<2, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            case 3: return launch_fused_mt<3, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            case 4: return launch_fused_mt<4, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            case 5: return launch_fused_mt<5, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            case 6: return launch_fused_mt<6, TW, 1, F16>(x, packed, y, B, M, K, G, s);
-            default: return launch_fused_mt<7, TW, 1, F16>(x, packed, y, B, M, K, G, s);
+            case 1: return launch_fused_mt<1, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 2: return launch_fused_mt<2, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 3: return launch_fused_mt<3, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 4: return launch_fused_mt<4, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 5: return launch_fused_mt<5, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            case 6: return launch_fused_mt<6, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+            default: return launch_fused_mt<7, TW, 1, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
         }
     }
     const int ngrp = (tiles + 13) / 14;
     const int mt = ((tiles + ngrp - 1) / ngrp + 1) / 2;  // row tiles per slab
     switch (mt) {
-        case 4: return launch_fused_mt<4, TW, 2, F16>(x, packed, y, B, M, K, G, s);
-        case 5: return launch_fused_mt<5, TW, 2, F16>(x, packed, y, B, M, K, G, s);
-        case 6: return launch_fused_mt<6, TW, 2, F16>(x, packed, y, B, M, K, G, s);
-        default: return launch_fused_mt<7, TW, 2, F16>(x, packed, y, B, M, K, G, s);
+        case 4: return launch_fused_mt<4, TW, 2, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+        case 5: return launch_fused_mt<5, TW, 2, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+        case 6: return launch_fused_mt<6, TW, 2, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
+        default: return launch_fused_mt<7, TW, 2, F16, 1>(x, packed, y, B, M, K, G, dbg, s);
     }
 }
 
@@ -587,16 +632,20 @@ GFN_EXPORT int gfn_conv_block_fwd(const float *x, const float *packed, float *y,
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
     if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: C*G*G must fit 31 bits");
+    const int dbg = variant >> 8;  // ablation mask, honoured by -DGFN_ABLATE builds only
+#ifdef GFN_ABLATE
+    variant &= 0xff;
+#endif
     if (variant < 0 || variant > 3) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: variant must be 0..3 (got %d)", variant);
     const bool f16 = (variant & 2) != 0;
     const bool fused = !(variant & 1) && (G & 3) == 0;
     if (fused) {
         // tile width: full 128-byte rows where the map allows, narrower tiles for the 5*2^k grids
         if (G % 32 == 0 || G > 160)
-            return f16 ? launch_fused<32, true>(x, packed, y, B, M, C, G, s) : launch_fused<32, false>(x, packed, y, B, M, C, G, s);
+            return f16 ? launch_fused<32, true>(x, packed, y, B, M, C, G, dbg, s) : launch_fused<32, false>(x, packed, y, B, M, C, G, dbg, s);
         if (G % 16 == 0 || G > 64)
-            return f16 ? launch_fused<16, true>(x, packed, y, B, M, C, G, s) : launch_fused<16, false>(x, packed, y, B, M, C, G, s);
-        return f16 ? launch_fused<8, true>(x, packed, y, B, M, C, G, s) : launch_fused<8, false>(x, packed, y, B, M, C, G, s);
+            return f16 ? launch_fused<16, true>(x, packed, y, B, M, C, G, dbg, s) : launch_fused<16, false>(x, packed, y, B, M, C, G, dbg, s);
+        return f16 ? launch_fused<8, true>(x, packed, y, B, M, C, G, dbg, s) : launch_fused<8, false>(x, packed, y, B, M, C, G, dbg, s);
     }
     int nblk, mt;
     slab_shape(M, &nblk, &mt);

@@ -36,7 +36,8 @@ def _block_case(B, C, M, G, bias=True):
 # (B, C, M, G): the five refiner widths, every tile shape (G % 32 == 0 -> 4x32 cells, G % 16 -> 8x16,
 # else 16x8), ragged channel counts, partial edge tiles, G not a multiple of 4 (two-pass form)
 CASES = [(2, 24, 24, 64), (1, 73, 73, 40), (1, 417, 417, 32), (1, 361, 361, 16), (1, 177, 177, 80), (3, 5, 9, 8), (2, 8, 8, 4),
-         (1, 33, 70, 12), (1, 24, 24, 160), (2, 16, 16, 20), (1, 225, 100, 24), (2, 22, 22, 10), (1, 7, 7, 5), (1, 40, 33, 48)]
+         (1, 33, 70, 12), (1, 24, 24, 160), (2, 16, 16, 20), (1, 225, 100, 24), (2, 22, 22, 10), (1, 7, 7, 5), (1, 40, 33, 48),
+         (1, 73, 73, 128), (2, 24, 24, 80), (1, 90, 96, 32)]
 
 
 @pytest.mark.parametrize("B,C,M,G", CASES)

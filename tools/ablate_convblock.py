@@ -6,8 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gfnet_amd import ops
 
-MASKS = [(0, "full"), (1, "-global loads"), (2, "-depthwise"), (4, "-mfma"), (8, "-stores"), (16, "-commit"), (2 | 4, "-dw -mfma"),
-         (1 | 16, "-loads -commit"), (1 | 2 | 16, "only mfma+stores"), (1 | 4 | 16 | 8, "only depthwise"), (31, "nothing")]
+MASKS = [(0, "full"), (1, "-global loads"), (2, "-depthwise"), (4, "-mfma"), (8, "-stores"), (16, "-commit"), (32, "-zero"), (2 | 4, "-dw -mfma"),
+         (1 | 16, "-loads -commit"), (1 | 2 | 16, "only mfma+stores"), (1 | 4 | 16 | 8, "only depthwise"), (1 | 2 | 4 | 16, "only stores"),
+         (2 | 4 | 8, "only loads+commit"), (63, "nothing")]
+PREC = int(os.environ.get("ABLATE_VARIANT", "2"))
 shapes = [(417, 32), (177, 64), (73, 128), (24, 256)]
 B = 64
 for C, G in shapes:
@@ -19,12 +21,12 @@ for C, G in shapes:
     for rnd in range(3):
         for m, name in MASKS:
             for _ in range(2):
-                ops.conv_block(x, packed, C, out=y, variant=m << 8)
+                ops.conv_block(x, packed, C, out=y, variant=(m << 8) | PREC)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.conv_block(x, packed, C, out=y, variant=m << 8)
+                ops.conv_block(x, packed, C, out=y, variant=(m << 8) | PREC)
             e1.record(); torch.cuda.synchronize()
             res.setdefault(name, []).append(e0.elapsed_time(e1) / 5 * 1e3)
-    print(f"C={C} G={G}: " + " | ".join(f"{n} {min(v):.0f}" for n, v in res.items()), flush=True)
+    print(f"variant {PREC} C={C} G={G}: " + " | ".join(f"{n} {min(v):.0f}" for n, v in res.items()), flush=True)
