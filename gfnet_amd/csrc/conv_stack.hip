@@ -19,6 +19,7 @@
 // A two-pass variant (dw5x5 kernel -> t in HBM -> GEMM kernel) computes bit-identical results; it
 // serves grids whose side is not a multiple of 4 and is the ablation/parity partner of the fused one.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -26,6 +27,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKT = 16;    // channels per K tile
 constexpr int kNP = 8;     // channel pairs per K tile
@@ -116,7 +119,7 @@ __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2
 //            tile W^T[k][m], the pairs' depthwise parameters        | barrier
 //   issue    global loads of the NEXT K tile into registers (land under the arithmetic below)
 //   depthwise  per thread 4/NS cells x one channel pair on packed fp32 (v_pk_fma_f32), relu, into the
-//            B operand tile Bs[pair][cell][2]                        | barrier
+//            B operand tile Bs[channel][cell]                        | barrier
 //   matrix   8 k-steps x MT v_mfma_f32_32x32x2_f32 per wave
 // Halo cells outside the map are zeroed once in LDS and never written (zero padding for free).
 template <int MT, int TW, int NS, bool F16, int NB>
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                                                                                const float *__restrict__ packed,
                                                                                float *__restrict__ y, int M, int K, int G,
                                                                                int tiles_x, int tiles_y, int ngrp, unsigned nwork,
-                                                                               int dbg_arg) {
+                                                                               int tpb, int dbg_arg) {
 #ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
     const int dbg = dbg_arg;
 #else
@@ -149,11 +152,17 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     constexpr int RB = NB;                  //            rows per thread
     constexpr int TPP = kBN / CPT;          //            threads per channel pair
     constexpr int GPR = TW / CPT;           //            threads per tile row
+    // Two-row depthwise threads step through the halo two rows at a time, and two row pitches are 0 mod 8 banks:
+    // every other row PAIR is stored 16 bytes later (the pitch has the room), which puts the 16 lanes of one
+    // ds_read_b128 group back on all 32 banks (measured: 69% of LDS cycles were bank conflicts without it).
+    constexpr bool SWZ = NB == 2;
 
     __shared__ __attribute__((aligned(16))) float Xs[kNP * PP];
     // fp32: [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3;  fp16: [buf][kg*BMS + m] = 8 halfs k = 8kg ..
     __shared__ float4 As4[2][GP * BMS];
-    __shared__ __attribute__((aligned(16))) float Bs[F16 ? BN * 8 : kNP * BN * 2];  // fp32 [pair][cell][2] / fp16 [k half][cell][8]
+    // B operand tile: fp32 [channel k][cell]; fp16 [pair][cell] of half2 (channels 2p, 2p+1) -- consecutive depthwise
+    // threads write consecutive 16-byte pieces, the matrix lanes read consecutive dwords
+    __shared__ __attribute__((aligned(16))) float Bs[F16 ? kNP * BN : kKT * BN];
     __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
 
     const PackDims pd(K, M);
@@ -164,30 +173,52 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     const int plane = G * G;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned L = gfn::xcd_remap(blockIdx.x, nwork);
-    const int grp = (int)(L % (unsigned)ngrp);
-    L /= (unsigned)ngrp;
-    const int tx = (int)(L % (unsigned)tiles_x);
-    L /= (unsigned)tiles_x;
-    const int ty = (int)(L % (unsigned)tiles_y);
-    const int b = (int)(L / (unsigned)tiles_y);
-    const int row0 = ty * TH, col0 = tx * TW, m0 = grp * BMS;
-    const float *xb = x + (size_t)b * K * plane;
+    // a workgroup walks `tpb` consecutive work items (cell tile x slab group); the (item, K tile) pairs form one
+    // pipeline, so only the first item's load latency is exposed
+    const unsigned lb = gfn::xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned w_begin = lb * (unsigned)tpb;
+    const unsigned w_end = w_begin + (unsigned)tpb < nwork ? w_begin + (unsigned)tpb : nwork;
+    const int nk = Kp / kKT;
+    const int total = (int)(w_end - w_begin) * nk;
+    auto decode = [&](unsigned item, int &b, int &row0, int &col0, int &m0) {
+        const unsigned grp = item % (unsigned)ngrp;
+        item /= (unsigned)ngrp;
+        const unsigned tx = item % (unsigned)tiles_x;
+        item /= (unsigned)tiles_x;
+        const unsigned ty = item % (unsigned)tiles_y;
+        b = (int)(item / (unsigned)tiles_y);
+        row0 = (int)ty * TH, col0 = (int)tx * TW, m0 = (int)grp * BMS;
+    };
 
-    // staging slots of this thread (fixed for the whole kernel)
-    int xg[XPP], xl[XPP], xp2[XPP];
-    bool xv[XPP];
+    // staging slots of this thread: LDS side fixed, global side per item
+    int xl[XPP], xp2[XPP], xg[XPP];
 #pragma unroll
     for (int i = 0; i < XPP; ++i) {
         const int e = tid + NT * i;
         const int p = e / (HR * RV4), rem = e - p * (HR * RV4);
         const int hr = rem / RV4, q = rem - hr * RV4;
-        const int gy = row0 - 2 + hr, gx = col0 - 4 + 4 * q;
-        xv[i] = e < PS && (unsigned)gy < (unsigned)G && gx >= 0 && gx < G;  // G % 4 == 0: the 4 cells are in or out together
-        xg[i] = xv[i] ? gy * G + gx : 0;
         xp2[i] = 2 * p;
-        xl[i] = p * PP + hr * RPP + 8 * q;
+        xl[i] = p * PP + hr * RPP + 8 * q + (SWZ && ((hr >> 1) & 1) ? 4 : 0);
     }
+    unsigned l_item = w_begin;  // load stage: the (item, K tile) the next issue() fetches
+    int l_kt = 0, l_m0 = 0, l_valid = 0;  // l_valid bit i: slot i lies inside the map (else zero padding)
+    const float *l_xb = x;
+    auto load_stage_enter_item = [&]() {
+        int b, row0, col0;
+        decode(l_item, b, row0, col0, l_m0);
+        l_xb = x + (size_t)b * K * plane;
+        l_valid = 0;
+#pragma unroll
+        for (int i = 0; i < XPP; ++i) {
+            const int e = tid + NT * i;
+            const int p = e / (HR * RV4), rem = e - p * (HR * RV4);
+            const int hr = rem / RV4, q = rem - hr * RV4;
+            const int gy = row0 - 2 + hr, gx = col0 - 4 + 4 * q;
+            const bool ok = e < PS && (unsigned)gy < (unsigned)G && gx >= 0 && gx < G;  // G % 4 == 0: 4 cells in or out together
+            xg[i] = ok ? gy * G + gx : 0;
+            l_valid |= ok ? 1 << i : 0;
+        }
+    };
     if (!(dbg & 32))
         for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -195,43 +226,52 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     float4 xr0[XPP], xr1[XPP];
     float4 ar0, ar1, ar2, ar3;  // named, not an array: the compiler demotes a float4 array here to LDS
     float pr[PPT];
+    int r_valid = 0;  // l_valid of the item in the registers; bit 8: its first K tile (refresh the zero padding)
     const float4 *wt4 = reinterpret_cast<const float4 *>(F16 ? packed + pd.wt16_off() : wt);
-    auto a_load = [&](int k0, int i) {
+    auto a_load = [&](int kt, int i) {
         const int e = tid + NT * i;
-        const int g = e / BMS, m = m0 + e - g * BMS;
+        const int g = e / BMS, m = l_m0 + e - g * BMS;
         const bool ok = e < AV4 && m < Mp;
-        return wt4[(size_t)((k0 >> 4) * GP + (ok ? g : 0)) * Mp + (ok ? m : 0)];
+        return wt4[(size_t)(kt * GP + (ok ? g : 0)) * Mp + (ok ? m : 0)];
     };
     auto a_store = [&](int buf, int i, const float4 &v) {
         const int e = tid + NT * i;
         if (e < AV4) As4[buf][e] = v;
     };
-    auto issue = [&](int k0) {
+    auto issue = [&]() {  // fetch (l_item, l_kt) into registers, advance the load stage
         if (dbg & 1) return;
+        const int k0 = l_kt * kKT;
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
             const int c0 = min(k0 + xp2[i], K - 1), c1 = min(k0 + xp2[i] + 1, K - 1);  // past C: any finite data, its taps are 0
-            xr0[i] = *reinterpret_cast<const float4 *>(xb + c0 * plane + xg[i]);
-            xr1[i] = *reinterpret_cast<const float4 *>(xb + c1 * plane + xg[i]);
+            xr0[i] = *reinterpret_cast<const float4 *>(l_xb + c0 * plane + xg[i]);
+            xr1[i] = *reinterpret_cast<const float4 *>(l_xb + c1 * plane + xg[i]);
         }
-        if constexpr (APT > 0) ar0 = a_load(k0, 0);
-        if constexpr (APT > 1) ar1 = a_load(k0, 1);
-        if constexpr (APT > 2) ar2 = a_load(k0, 2);
-        if constexpr (APT > 3) ar3 = a_load(k0, 3);
+        if constexpr (APT > 0) ar0 = a_load(l_kt, 0);
+        if constexpr (APT > 1) ar1 = a_load(l_kt, 1);
+        if constexpr (APT > 2) ar2 = a_load(l_kt, 2);
+        if constexpr (APT > 3) ar3 = a_load(l_kt, 3);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
+        r_valid = l_valid | (l_kt == 0 && l_item != w_begin ? 256 : 0);
+        if (++l_kt == nk) {
+            l_kt = 0;
+            if (++l_item < w_end) load_stage_enter_item();
+        }
     };
     auto commit = [&](int buf) {
         if (dbg & 16) return;
 #pragma unroll
-        for (int i = 0; i < XPP; ++i)
-            if (xv[i]) {
-                float4 lo, hi;
-                lo.x = xr0[i].x, lo.y = xr1[i].x, lo.z = xr0[i].y, lo.w = xr1[i].y;
-                hi.x = xr0[i].z, hi.y = xr1[i].z, hi.z = xr0[i].w, hi.w = xr1[i].w;
-                *reinterpret_cast<float4 *>(&Xs[xl[i]]) = lo;
-                *reinterpret_cast<float4 *>(&Xs[xl[i] + 4]) = hi;
+        for (int i = 0; i < XPP; ++i) {
+            if (r_valid & (1 << i)) {
+                const f32x4 lo = {xr0[i].x, xr1[i].x, xr0[i].y, xr1[i].y}, hi = {xr0[i].z, xr1[i].z, xr0[i].w, xr1[i].w};
+                *reinterpret_cast<f32x4 *>(&Xs[xl[i]]) = lo;
+                *reinterpret_cast<f32x4 *>(&Xs[xl[i] + 4]) = hi;
+            } else if ((r_valid & 256) && tid + NT * i < PS) {  // outside the map: re-zero once per item after the first
+                *reinterpret_cast<float4 *>(&Xs[xl[i]]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&Xs[xl[i] + 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
         if constexpr (APT > 0) a_store(buf, 0, ar0);
         if constexpr (APT > 1) a_store(buf, 1, ar1);
         if constexpr (APT > 2) a_store(buf, 2, ar2);
@@ -249,18 +289,31 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     const int col = lane & 31, kh = lane >> 5;
     const int slab = wave >> 2, cw = wave & 3;  // matrix role: output slab, 32-cell group (of each 128-cell half)
     // depthwise role: channel pair dp, tile rows dr .. dr+RB-1, cells dc .. dc+CPT-1
-    const int dp = tid / TPP, dg = tid - dp * TPP, dr = (dg / GPR) * RB, dc = (dg - (dg / GPR) * GPR) * CPT;
-    const float *dw_src = &Xs[dp * PP + dr * RPP + 2 * (dc + 2)];  // staged cell index = tile cell + 4; taps reach cells dc-2 ..
+    // The LDS serves a ds_read_b128 in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with 32-wide tiles the
+    // lanes of one group are given one row (2-cell threads) or two rows (4-cell threads) of a channel pair, so that their
+    // reads are consecutive 16-byte units (measured 4.8 vs 8.5 LDS cycles per read instruction with lanes in natural order)
+    const int l32 = lane & 31;
+    const int lperm = TW == 32 ? (int)((0x73261540u >> (4 * (l32 >> 2))) & 7u) * 4 + (l32 & 3) + (lane & 32) : lane;
+    const int dtid = (tid & ~63) | lperm;
+    const int dp = dtid / TPP, dg = dtid - dp * TPP, dr = (dg / GPR) * RB, dc = (dg - (dg / GPR) * GPR) * CPT;
+    // staged cell index = tile cell + 4; taps reach cells dc-2 ..; dw_src: halo rows hy with (hy>>1) even, dw_src1: odd (see SWZ)
+    const int dw_shift = SWZ ? 4 * ((dr >> 1) & 1) : 0;
+    const float *dw_src = &Xs[dp * PP + dr * RPP + 2 * (dc + 2) + dw_shift];
+    const float *dw_src1 = &Xs[dp * PP + dr * RPP + 2 * (dc + 2) + (SWZ ? 4 - dw_shift : 0)];
     const f32x2 *dw_par = reinterpret_cast<const f32x2 *>(&Ps[dp * kCP2]);
-    float *dw_dst = &Bs[F16 ? 0 : (dp * BN + dr * TW + dc) * 2];
+    float *dw_dst = &Bs[(F16 ? dp : 2 * dp) * BN + dr * TW + dc];  // fp32: channel 2dp here, 2dp+1 one plane (BN) further
 
-    issue(0);
+    if (total <= 0) return;
+    load_stage_enter_item();
+    issue();
     __syncthreads();  // Xs zeroed
-    int buf = 0;
-    for (int k0 = 0; k0 < Kp; k0 += kKT, buf ^= 1) {
+    unsigned c_item = w_begin;  // the item being accumulated
+    int c_kt = 0;
+    for (int t = 0; t < total; ++t) {
+        const int buf = t & 1;
         commit(buf);
         __syncthreads();
-        if (k0 + kKT < Kp) issue(k0 + kKT);
+        if (t + 1 < total) issue();
         if (!(dbg & 2)) {  // depthwise: RB output rows x CPT cells x one channel pair; every halo row and every tap row is read once
             f32x2 a[RB][CPT];
 #pragma unroll
@@ -273,7 +326,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                 f32x2 v[CPT + 4];
 #pragma unroll
                 for (int q = 0; q < (CPT + 4) / 2; ++q) {
-                    const float4 f = *reinterpret_cast<const float4 *>(dw_src + hy * RPP + 4 * q);
+                    const float4 f = *reinterpret_cast<const float4 *>((((hy >> 1) & 1) ? dw_src1 : dw_src) + hy * RPP + 4 * q);
                     v[2 * q] = f32x2{f.x, f.y};
                     v[2 * q + 1] = f32x2{f.z, f.w};
                 }
@@ -294,19 +347,25 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             const f32x2 cb = dw_par[25], al = dw_par[26], be = dw_par[27];
 #pragma unroll
             for (int ro = 0; ro < RB; ++ro) {
-                if constexpr (F16) {  // B operand tile in fp16: [k half kg][cell][8], the pair's two channels side by side
-                    f16x2 *dst16 = reinterpret_cast<f16x2 *>(Bs) + (((dp >> 2) * BN + (dr + ro) * TW + dc) * 4 + (dp & 3));
+                f32x2 t[CPT];
 #pragma unroll
-                    for (int j = 0; j < CPT; ++j) {
-                        const f32x2 t = dw_finish2(a[ro][j], cb, al, be);
-                        dst16[4 * j] = f16x2{(_Float16)t.x, (_Float16)t.y};
+                for (int j = 0; j < CPT; ++j) t[j] = dw_finish2(a[ro][j], cb, al, be);
+                float *dst = dw_dst + ro * TW;
+                if constexpr (F16) {  // CPT cells x half2: one 16-byte (8-byte) write
+                    if constexpr (CPT == 4) {
+                        const f16x8 h = {(_Float16)t[0].x, (_Float16)t[0].y, (_Float16)t[1].x, (_Float16)t[1].y,
+                                         (_Float16)t[2].x, (_Float16)t[2].y, (_Float16)t[3].x, (_Float16)t[3].y};
+                        *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, h);
+                    } else {
+                        const f16x4 h = {(_Float16)t[0].x, (_Float16)t[0].y, (_Float16)t[1].x, (_Float16)t[1].y};
+                        *reinterpret_cast<f32x2 *>(dst) = __builtin_bit_cast(f32x2, h);
                     }
+                } else if constexpr (CPT == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(t[0].x, t[1].x, t[2].x, t[3].x);
+                    *reinterpret_cast<float4 *>(dst + BN) = make_float4(t[0].y, t[1].y, t[2].y, t[3].y);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < CPT; j += 2) {
-                        const f32x2 t0 = dw_finish2(a[ro][j], cb, al, be), t1 = dw_finish2(a[ro][j + 1], cb, al, be);
-                        *reinterpret_cast<float4 *>(dw_dst + 2 * (ro * TW + j)) = make_float4(t0.x, t0.y, t1.x, t1.y);
-                    }
+                    *reinterpret_cast<float2 *>(dst) = make_float2(t[0].x, t[1].x);
+                    *reinterpret_cast<float2 *>(dst + BN) = make_float2(t[0].y, t[1].y);
                 }
             }
         }
@@ -316,7 +375,10 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             if (dbg & 4) break;
             const int cell = (g * 4 + cw) * 32 + col;  // this lane's B column
             if constexpr (F16) {  // one v_mfma_f32_32x32x16_f16 per row tile: lane (n or m = lane&31, kg = lane>>5) holds 8 halfs
-                const f16x8 bv = reinterpret_cast<const f16x8 *>(Bs)[kh * BN + cell];
+                // channel pairs 4kh .. 4kh+3 of this cell = halfs k = 8kh .. 8kh+7
+                const float *bp = &Bs[4 * kh * BN + cell];
+                const f32x4 bq = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
+                const f16x8 bv = __builtin_bit_cast(f16x8, bq);
                 const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][kh * BMS + slab * BM + col]);
                 f16x8 av[MT];
 #pragma unroll
@@ -326,7 +388,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             } else {
                 // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
                 // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
-                const float *bsrc = &Bs[cell * 2 + kh];  // t[2s+kh][cell] at + s*2*BN
+                const float *bsrc = &Bs[kh * BN + cell];  // t[2s+kh][cell] at + s*2*BN
                 const float4 *asrc = &As4[buf][kh * BMS + slab * BM + col];
                 float bv[8];
                 float4 av[MT];
@@ -355,8 +417,12 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                 }
             }
         }
-    }
-    // D[row][col]: col = lane&31 -> cell (g*4+cw)*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (++c_kt < nk) continue;
+        // item finished: D[row][col], col = lane&31 -> cell (g*4+cw)*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        int b, row0, col0, m0;
+        decode(c_item, b, row0, col0, m0);
+        c_kt = 0;
+        ++c_item;
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         const int p = (g * 4 + cw) * 32 + col;
@@ -390,6 +456,11 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                 }
             }
         }
+    }
+#pragma unroll
+        for (int i = 0; i < NB * MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     }
 }
 
@@ -560,6 +631,12 @@ inline void slab_shape(int M, int *nblk, int *mt) {
     *mt = (tiles + *nblk - 1) / *nblk;
 }
 
+// GFN_CONV_TPB (environment, experiments): work items per workgroup of the fused kernel, 0 = heuristic
+static int g_conv_tpb = [] {
+    const char *e = getenv("GFN_CONV_TPB");
+    return e ? atoi(e) : 0;
+}();
+
 template <int MT, int TW, int NS, bool F16, int NB>
 int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     constexpr int TH = kBN * NB / TW;
@@ -567,8 +644,12 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
     const int ngrp = (M + 32 * MT * NS - 1) / (32 * MT * NS);
     const long nwork = (long)B * tiles_x * tiles_y * ngrp;
     if (nwork > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: too many tiles");
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB>), dim3((unsigned)nwork), dim3(256 * NS), 0, s, x, packed, y, M, K, G,
-                       tiles_x, tiles_y, ngrp, (unsigned)nwork, dbg);
+    // work items per workgroup (pipelined back to back)
+    int tpb = nwork >= 16384 ? 2 : 1;  // measured: pays only on the largest grids
+    if (g_conv_tpb > 0) tpb = g_conv_tpb;
+    const unsigned grid = (unsigned)((nwork + tpb - 1) / tpb);
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
+                       tiles_y, ngrp, (unsigned)nwork, tpb, dbg);
     return gfn::check_launch("dwpw_fused_kernel");
 }
 

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 $ROOT/tools/probe_convblock.py $C $G $B 0 2 > $OUT/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 $ROOT/tools/probe_convblock.py $C $G $B ${PMC_VARIANT:-0} 2 > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
