@@ -72,6 +72,7 @@ class ConvRefiner(nn.Module):
         # 1x1 conv operands on the HIP path: "fp32" (exact fp32 products, the CPU reference's class) or "fp16"
         # (operands rounded to fp16, fp32 accumulation: the autocast class the reference runs these refiners in on GPU)
         self.conv_precision = "fp32"
+        self.fold_out_conv = True  # multiply out_conv into the last block's 1x1 conv (see folded_stack)
 
     def assemble(self, num_grid, x, y, flow, scale_factor=1):
         """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view."""
@@ -97,28 +98,35 @@ class ConvRefiner(nn.Module):
 
     def folded_stack(self):
         """Per block the packed parameters of ops.conv_block (eval-mode BatchNorm folded to
-        y = x*alpha + beta in float64), and out_conv's (W, bias); cached until a parameter or running
-        statistic changes."""
+        y = x*alpha + beta in float64); cached until a parameter or running statistic changes.
+        out_conv follows the last block's 1x1 conv with nothing in between (network.py:487,563), so the
+        two linear maps are multiplied out in float64 (W = W_out W_pw, b = W_out b_pw + b_out): the last
+        block writes the 3 output channels directly instead of C channels that out_conv re-reads."""
         blocks = [self.block1] + list(self.hidden_blocks)
         key = tuple(t._version for blk in blocks for t in list(blk.parameters()) + list(blk.buffers())) + \
-            tuple(p._version for p in self.out_conv.parameters()) + (str(self.out_conv.weight.device),)
+            tuple(p._version for p in self.out_conv.parameters()) + (str(self.out_conv.weight.device), self.fold_out_conv)
         if getattr(self, "_fold_key", None) == key:
             return self._fold
         fold = []
         with torch.no_grad():
-            for conv, norm, _, pw in blocks:
+            oc = self.out_conv
+            ow = oc.weight.float().reshape(oc.out_channels, oc.in_channels).contiguous()
+            ob = oc.bias.float().contiguous()
+            for n, (conv, norm, _, pw) in enumerate(blocks):
                 alpha = (norm.weight.double() / torch.sqrt(norm.running_var.double() + norm.eps)).float()
                 beta = (norm.bias.double() - norm.running_mean.double() * alpha.double()).float()
-                fold.append((ops.conv_block_pack(conv.weight, conv.bias, alpha, beta, pw.weight, pw.bias), pw.out_channels))
-            oc = self.out_conv
-            out = (oc.weight.float().reshape(oc.out_channels, oc.in_channels).contiguous(), oc.bias.float().contiguous())
-        self._fold_key, self._fold = key, (fold, out)
+                pw_w, pw_b = pw.weight.reshape(pw.out_channels, -1), pw.bias
+                if self.fold_out_conv and n == len(blocks) - 1:
+                    pw_b = (ow.double() @ pw_b.double() + ob.double()).float()
+                    pw_w = (ow.double() @ pw_w.double()).float()
+                fold.append((ops.conv_block_pack(conv.weight, conv.bias, alpha, beta, pw_w, pw_b), pw_w.shape[0]))
+        self._fold_key, self._fold = key, (fold, None if self.fold_out_conv else (ow, ob))
         return self._fold
 
     def conv_stack(self, d, variant=None):
         """out_conv(hidden_blocks(block1(d))), network.py:560-563, on csrc/conv_stack.hip: one fused
         kernel per block, two ping-pong maps."""
-        fold, (ow, ob) = self.folded_stack()
+        fold, out_conv = self.folded_stack()
         if variant is None:
             if self.conv_precision not in ("fp32", "fp16"):
                 raise ValueError("conv_precision must be 'fp32' or 'fp16'")
@@ -128,7 +136,7 @@ class ConvRefiner(nn.Module):
             if bufs[i & 1] is None or bufs[i & 1].shape[1] != M:
                 bufs[i & 1] = torch.empty((d.shape[0], M) + tuple(d.shape[2:]), device=d.device, dtype=torch.float32)
             x = ops.conv_block(x, packed, M, out=bufs[i & 1], variant=variant)
-        return ops.pointwise_conv(x, ow, ob)
+        return x if out_conv is None else ops.pointwise_conv(x, out_conv[0], out_conv[1])
 
     def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None):
         d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor)

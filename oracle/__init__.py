@@ -369,3 +369,48 @@ def homography_dlt_svd(pts, weight=None):
     _, _, Vt = np.linalg.svd(np.array(rows))
     H = np.linalg.inv(Tb) @ Vt[-1].reshape(3, 3) @ Ta
     return H / H[2, 2]
+
+
+# ---- refiner conv stack ---------------------------------------------------------
+def conv_block(x, dw_w, dw_b, bn_weight, bn_bias, bn_mean, bn_var, pw_w, pw_b, eps=1e-5, variant="f32"):
+    """One ConvRefiner block in eval mode -- model/network.py:471-487 (create_block):
+    Conv2d(C, C, 5, padding 2, groups=C) -> BatchNorm2d (running statistics) -> ReLU -> Conv2d(C, M, 1).
+    x (B,C,G,G); dw_w (C,1,5,5) or (C,25); dw_b (C) or None; pw_w (M,C[,1,1]); pw_b (M)."""
+    rt = _real(variant)
+    x = np.asarray(x, rt)
+    B, C, G, G2 = x.shape
+    w = np.asarray(dw_w, rt).reshape(C, 5, 5)
+    xp = np.zeros((B, C, G + 4, G2 + 4), rt)
+    xp[:, :, 2:-2, 2:-2] = x
+    t = np.zeros_like(x)
+    for dy in range(5):          # cross-correlation, as torch's conv2d: out[i,j] += w[dy,dx] * x[i+dy-2, j+dx-2]
+        for dx in range(5):
+            t += w[None, :, dy, dx, None, None] * xp[:, :, dy:dy + G, dx:dx + G2]
+    if dw_b is not None:
+        t += np.asarray(dw_b, rt)[None, :, None, None]
+    inv = (1.0 / np.sqrt(np.asarray(bn_var, rt) + rt(eps))).astype(rt)       # ATen batch_norm, eval
+    t = (t - np.asarray(bn_mean, rt)[None, :, None, None]) * inv[None, :, None, None] * np.asarray(bn_weight, rt)[None, :, None, None] \
+        + np.asarray(bn_bias, rt)[None, :, None, None]
+    t = np.maximum(t, 0)
+    M = np.asarray(pw_w).shape[0]
+    y = np.einsum("mc,bcij->bmij", np.asarray(pw_w, rt).reshape(M, C), t) + np.asarray(pw_b, rt)[None, :, None, None]
+    return y.astype(rt)
+
+
+def conv_stack(d, sd, variant="f32"):
+    """out_conv(hidden_blocks(block1(d))) -- ConvRefiner.forward, model/network.py:560-563, from a
+    ConvRefiner state_dict `sd` (reference parameter names: block1.{0,1,3}.*, hidden_blocks.N.{0,1,3}.*,
+    out_conv.*).  Returns (B, out_dim, G, G)."""
+    def block(prefix, h):
+        return conv_block(h, sd[prefix + ".0.weight"], sd.get(prefix + ".0.bias"), sd[prefix + ".1.weight"], sd[prefix + ".1.bias"],
+                          sd[prefix + ".1.running_mean"], sd[prefix + ".1.running_var"], sd[prefix + ".3.weight"],
+                          sd[prefix + ".3.bias"], variant=variant)
+    h = block("block1", d)
+    n = 0
+    while f"hidden_blocks.{n}.0.weight" in sd:
+        h = block(f"hidden_blocks.{n}", h)
+        n += 1
+    rt = _real(variant)
+    ow = np.asarray(sd["out_conv.weight"], rt)
+    ow = ow.reshape(ow.shape[0], -1)
+    return (np.einsum("mc,bcij->bmij", ow, h) + np.asarray(sd["out_conv.bias"], rt)[None, :, None, None]).astype(rt)

@@ -1,5 +1,6 @@
 """GPU: the refiner conv stack (csrc/conv_stack.hip) against torch's convs of the same
 layers (model/network.py:471-487, 560-563) through the C ABI."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -133,6 +134,12 @@ def test_conv_stack_matches_torch_modules(feat, disp, r, G, B):
     err, mag = _maxerr(got, want)
     assert err <= 1e-4 * max(mag, 1.0), (err, mag)
     assert torch.equal(got, got2)
+    with torch.no_grad():  # out_conv as its own kernel instead of multiplied into the last block
+        ref.fold_out_conv = False
+        unfolded = ref.conv_stack(d)
+        ref.fold_out_conv = True
+    err, _ = _maxerr(unfolded, want)
+    assert err <= 1e-4 * max(mag, 1.0), (err, mag)
     # fp16 operands: closer to the fp32 result than torch's own fp16 autocast of the same modules is
     err16, _ = _maxerr(got16, want)
     err_amp, _ = _maxerr(want16, want)
@@ -142,6 +149,32 @@ def test_conv_stack_matches_torch_modules(feat, disp, r, G, B):
     with torch.no_grad():
         ref.block1[1].running_mean.add_(0.5)
         assert not torch.equal(ref.conv_stack(d), got)
+
+
+@pytest.mark.parametrize("feat,disp,r,G,B", [(8, 8, 0, 24, 2), (16, 16, 2, 12, 1), (8, 6, 2, 10, 2)])
+def test_conv_stack_matches_oracle(feat, disp, r, G, B):
+    """HIP stack (C ABI) against the CPU oracle's restatement (pinned on the reference's golden G4 in
+    tests/test_oracle_golden.py), same state_dict and input; G = 10 takes the two-pass kernels."""
+    import oracle
+    from gfnet_amd.model.network import _refiner_for
+
+    torch.manual_seed(11)
+    ref = _refiner_for(feat, disp, r).cuda().eval()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    C = ref.block1[0].in_channels
+    d = _rand(B, C, G, G, seed=31)
+    sd = {k: v.detach().cpu().numpy() for k, v in ref.state_dict().items()}
+    want = oracle.conv_stack(d.cpu().numpy(), sd, variant="f64")
+    with torch.no_grad():
+        got = ref.conv_stack(d)
+    err = float(np.abs(got.cpu().numpy().astype(np.float64) - want).max())
+    assert err <= 1e-4 * max(float(np.abs(want).max()), 1.0), err
 
 
 def test_training_mode_uses_torch_modules():

@@ -137,6 +137,20 @@ def test_g4_refiner_input_concat():
     assert_close(d1, g["d_nocorr"], 1e-5, "d (no corr)")
 
 
+def test_g4_conv_stack_matches_reference():
+    """the refiner conv stack (model/network.py:471-487, 560-563) restated in numpy, pinned on the
+    reference's own delta_flow / delta_certainty for the golden refiners (non-trivial BatchNorm statistics)."""
+    g = load_golden("g4_refiner_prefix")
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    out = oracle.conv_stack(g["d"], sd)
+    assert_close(out[:, :2], g["delta_flow"], 1e-6, "delta_flow")
+    assert_close(out[:, 2:3], g["delta_cert"], 1e-6, "delta_cert")
+    sd1 = {k[4:]: g[k] for k in g.files if k.startswith("sd1.")}
+    out1 = oracle.conv_stack(g["d_nocorr"], sd1)
+    assert_close(out1[:, :2], g["delta_flow_nocorr"], 1e-6, "delta_flow (no corr)")
+    assert_close(out1[:, 2:3], g["delta_cert_nocorr"], 1e-6, "delta_cert (no corr)")
+
+
 # ---- G5 (interpolate part) / G6: match post-processing (model/network.py:326-384) -------------
 def test_interpolate_matches_forward_loop_golden():
     g = load_golden("g5_forward_loop")
