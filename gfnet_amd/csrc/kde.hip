@@ -13,6 +13,7 @@
 // over blockIdx.y and the partial sums are reduced by a second tiny kernel (deterministic, no
 // float atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -182,6 +183,149 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_culled_kernel(const float *_
     if (n < N) part[((size_t)bt * MS + ms) * N + n] = acc.x + acc.y;
 }
 
+// ---- matrix-core variant of the culled kernel --------------------------------------------------------
+// The exponent |x-y|^2 = |x|^2 + |y|^2 - 2 x.y of a 32 x 32 tile of (query, point) pairs is one pair of
+// v_mfma_f32_32x32x16_bf16: every fp32 coordinate is split into three bf16 pieces (8+8+8 mantissa bits,
+// exact), the products that matter (h.h, h.l, l.h, h.ll, ll.h, l.l per axis: 24 slots) and the squared
+// norms (3 + 3 slots against ones) fill K = 32, so D comes out as the exponent itself (error ~1e-5 from the
+// fp32 accumulation of +-300 magnitudes, i.e. 1e-5 relative on a term).  What is left on the VALU per pair
+// is v_exp_f32 and half a packed add -- 2.4x fewer vector cycles than the difference form above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &l, __bf16 &ll) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    l = (__bf16)r1;
+    ll = (__bf16)(r1 - (float)l);
+}
+
+// Operand images: op[(bt*T + tile)*4 + g][row 0..31] = 8 bf16, g = MFMA (0/1) * 2 + k half; one thread per point.
+//   MFMA 0  k 0-7 : A xh  nxh 1 nxl 1   B yh  1 nyh 1 nyl      k 8-15: A xh xl    B yl yh
+//   MFMA 1  k 0-7 : A xh  xll           B yll yh               k 8-15: A xl  nxll 1 0 0   B yl  1 nyll 0 0
+// with y = -2 * (scaled point), nx = |x|^2, ny = |point|^2 (scaled).  The large terms (h.h products, leading pieces of
+// the norms) sit in ONE accumulation so that no intermediate sum is large (a +-400 intermediate cost 4e-5 relative on a
+// term; this order 1e-5).  Padding points get ny = 1e30 (term 0).
+__global__ __launch_bounds__(256) void kde4_operands_kernel(const float *__restrict__ xs, const float *__restrict__ ys,
+                                                            bf16x8 *__restrict__ aop, bf16x8 *__restrict__ bop, int N, int M, int Mp,
+                                                            int NT, int MT, int Bt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long na = (long)Bt * NT * 32, nb = (long)Bt * MT * 32;
+    const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+    if (idx < na) {
+        const int bt = (int)(idx / ((long)NT * 32)), n = (int)(idx - (long)bt * NT * 32);
+        __bf16 h[4], l[4], ll[4], nh = zero, nl = zero, nll = zero;
+        float nx = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float v = n < N ? xs[((size_t)bt * N + n) * 4 + d] : 0.f;
+            split3(v, h[d], l[d], ll[d]);
+            nx = fmaf(v, v, nx);
+        }
+        split3(nx, nh, nl, nll);
+        bf16x8 *dst = aop + ((size_t)bt * NT + (n >> 5)) * 4 * 32 + (n & 31);
+        dst[0] = bf16x8{h[0], h[1], h[2], h[3], nh, one, nl, one};
+        dst[32] = bf16x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
+        dst[64] = bf16x8{h[0], h[1], h[2], h[3], ll[0], ll[1], ll[2], ll[3]};
+        dst[96] = bf16x8{l[0], l[1], l[2], l[3], nll, one, zero, zero};
+    }
+    if (idx < nb) {
+        const int bt = (int)(idx / ((long)MT * 32)), m = (int)(idx - (long)bt * MT * 32);
+        __bf16 h[4], l[4], ll[4], nh, nl, nll;
+        float ny = 0.f;
+        const bool real = m < M;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float v = real ? ys[((size_t)bt * (Mp >> 1) + (m >> 1)) * 8 + d * 2 + (m & 1)] : 0.f;
+            split3(-2.f * v, h[d], l[d], ll[d]);
+            ny = fmaf(v, v, ny);
+        }
+        split3(real ? ny : 1e30f, nh, nl, nll);
+        bf16x8 *dst = bop + ((size_t)bt * MT + (m >> 5)) * 4 * 32 + (m & 31);
+        dst[0] = bf16x8{h[0], h[1], h[2], h[3], one, nh, one, nl};
+        dst[32] = bf16x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+        dst[64] = bf16x8{ll[0], ll[1], ll[2], ll[3], h[0], h[1], h[2], h[3]};
+        dst[96] = bf16x8{l[0], l[1], l[2], l[3], one, nll, zero, zero};
+    }
+}
+
+// One wave = 64 queries (two 32-row tiles); reference blocks of 64 points (two 32-column tiles) culled by their
+// bounding boxes as in kde4_culled_kernel.  Lane (col = lane&31, kh = lane>>5) accumulates its column of every tile;
+// the 32 columns are summed across lanes once at the end.
+__global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__restrict__ xs, const bf16x8 *__restrict__ aop,
+                                                                const bf16x8 *__restrict__ bop, const float *__restrict__ box,
+                                                                float *__restrict__ part, int N, int Mp, int NT, int MT) {
+    const int bt = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * kKdeThreads + wave * 64;
+    if (q0 >= N) return;
+    const int n = q0 + lane;
+    const int MS = gridDim.y, ms = blockIdx.y;
+    const int nblk = (Mp + 63) >> 6;
+    const int per = (nblk + MS - 1) / MS;
+    const int b0 = ms * per, b1 = min(nblk, b0 + per);
+    const float4 xv = (n < N) ? reinterpret_cast<const float4 *>(xs)[(size_t)bt * N + n] : make_float4(0, 0, 0, 0);
+    float qlo[4] = {xv.x, xv.y, xv.z, xv.w}, qhi[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (n >= N) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { qlo[d] = 3e38f; qhi[d] = -3e38f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            qlo[d] = fminf(qlo[d], __shfl_xor(qlo[d], o));
+            qhi[d] = fmaxf(qhi[d], __shfl_xor(qhi[d], o));
+        }
+    }
+    const int col = lane & 31, kh = lane >> 5;
+    const bf16x8 *ap = aop + ((size_t)bt * NT + (q0 >> 5)) * 128 + kh * 32 + col;
+    const bf16x8 a00 = ap[0], a01 = ap[64], a10 = ap[128], a11 = ap[192];  // [row tile][MFMA]
+    const bf16x8 *bp = bop + (size_t)bt * MT * 128 + kh * 32 + col;
+    const float *bx = box + (size_t)bt * nblk * 8;
+    f32x2 acc0[8], acc1[8];  // [r/2] = rows r, r+1 of the lane's column (packed adds)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc0[r] = f32x2{0.f, 0.f}, acc1[r] = f32x2{0.f, 0.f};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int blk = b0; blk < b1; ++blk) {
+        float d2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float g = fmaxf(fmaxf(qlo[d] - bx[blk * 8 + 4 + d], bx[blk * 8 + d] - qhi[d]), 0.f);
+            d2 = fmaf(g, g, d2);
+        }
+        if (d2 > kKdeCutoffLog2) continue;  // the same for every lane of the wave
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const bf16x8 *b = bp + (size_t)(blk * 2 + ct) * 128;
+            const bf16x8 bv0 = b[0], bv1 = b[64];
+            f32x16 e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, bv0, zero16, 0, 0, 0);
+            f32x16 e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, bv0, zero16, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, bv1, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, bv1, e1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0[r] += f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
+                acc1[r] += f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
+            }
+        }
+    }
+    // sum the 32 columns (lanes with the same kh), then lanes col == 0 hold rows (r&3) + 8(r>>2) + 4kh of each row tile
+    float *dst = part + ((size_t)bt * MS + ms) * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v0 = acc0[r >> 1][r & 1], v1 = acc1[r >> 1][r & 1];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            v0 += __shfl_xor(v0, o);
+            v1 += __shfl_xor(v1, o);
+        }
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (col == 0 && q0 + row < N) dst[q0 + row] = v0;
+        if (col == 0 && q0 + 32 + row < N) dst[q0 + 32 + row] = v1;
+    }
+}
+
 // any point dimension D (the reference never uses anything but 4)
 __global__ __launch_bounds__(kKdeThreads) void kde_generic_kernel(const float *__restrict__ x,
                                                                   const float *__restrict__ y, float *__restrict__ part,
@@ -261,7 +405,9 @@ GFN_EXPORT int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_str
 // Scratch floats for gfn_kde_density_sorted: pre-scaled copies, block boxes, split-M partials.
 GFN_EXPORT int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M) {
     const int Mp = (M + 1) & ~1;
-    return (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4 + (int64_t)Bt * ((Mp + 63) / 64) * 8 + (int64_t)Bt * 32 * N + 64;
+    const int64_t nblk = (Mp + 63) / 64, ntile = (N + 63) / 64 * 2;
+    return (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4 + Bt * nblk * 8 + (int64_t)Bt * 32 * N + 64 +
+           (Bt * ntile * 32 + Bt * nblk * 64) * 16 + 8;  // + the matrix-core operand images (64 B per query / point)
 }
 
 // Density of spatially sorted 4-D points (see kde4_culled_kernel): x (Bt,N,4), y (Bt,M,4), both in
@@ -288,9 +434,22 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
         while (blocks * MS < 2048 && nblk / (MS * 2) >= 8 && MS < 32) MS *= 2;
     }
     float *dst = MS > 1 ? part : out;
-    hipLaunchKernelGGL(kde4_culled_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, ys, box,
-                       dst, N, Mp);
-    if (int e = gfn::check_launch("kde4_culled_kernel")) return e;
+    static const bool valu_only = getenv("GFN_KDE_VALU") != nullptr;  // experiments: the difference-form kernel
+    if (valu_only) {
+        hipLaunchKernelGGL(kde4_culled_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, ys,
+                           box, dst, N, Mp);
+        if (int e = gfn::check_launch("kde4_culled_kernel")) return e;
+    } else {
+        const int NT = (N + 63) / 64 * 2, MT = nblk * 2;
+        float *opbase = part + (((int64_t)Bt * 32 * N + 3) & ~(int64_t)3);
+        bf16x8 *aop = reinterpret_cast<bf16x8 *>(opbase), *bop = aop + (int64_t)Bt * NT * 128;
+        const long npts = (long)Bt * 32 * (NT > MT ? NT : MT);
+        hipLaunchKernelGGL(kde4_operands_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, s, xs, ys, aop, bop, N, M, Mp, NT,
+                           MT, Bt);
+        hipLaunchKernelGGL(kde4_mfma_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, aop, bop,
+                           box, dst, N, Mp, NT, MT);
+        if (int e = gfn::check_launch("kde4_mfma_kernel")) return e;
+    }
     if (MS > 1) {
         const long total = (long)Bt * N;
         hipLaunchKernelGGL(kde_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, out, N, MS, Bt);

@@ -281,9 +281,14 @@ def test_kde_culled_equals_dense_and_oracle_on_match_like_points():
     x = np.concatenate((a, b), -1).astype(np.float32)
     dense = host(ops.kde_density(dev(x), std=0.1, cull=False))
     culled = host(ops.kde_density(dev(x), std=0.1, cull=True))
-    np.testing.assert_allclose(culled, dense, rtol=2e-5)
+    # the culled path forms the exponents on the matrix core (|x|^2 + |y|^2 - 2 x.y in bf16x3 pieces, fp32 accumulation):
+    # ~1e-5 relative on a term, against the difference form of the dense kernel
+    np.testing.assert_allclose(culled, dense, rtol=1e-4)
+    print("culled vs dense max rel", np.max(np.abs(culled - dense) / dense))
     for bt in range(Bt):
-        np.testing.assert_allclose(culled[bt], oracle.kde(x[bt], 0.1, half=False), rtol=1e-4)
+        ref = oracle.kde(x[bt], 0.1, half=False)
+        print("culled vs oracle max rel", np.max(np.abs(culled[bt] - ref) / ref), "dense vs oracle", np.max(np.abs(dense[bt] - ref) / ref))
+        np.testing.assert_allclose(culled[bt], ref, rtol=1e-4)
     # separate reference set (x[::8], the reference's CPU-branch subsampling)
     y = np.ascontiguousarray(x[:, ::8])
     c2 = host(ops.kde_density(dev(x), dev(y), std=0.1, cull=True))
