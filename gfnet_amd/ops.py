@@ -207,7 +207,12 @@ def _morton_sorted(pts, dev):
     Bt, N, _ = pts.shape
     keys = torch.empty((Bt, N), device=dev, dtype=torch.int32)
     check(_L().gfn_kde_morton_keys(ptr(pts), ptr(keys), Bt * N, stream_ptr(dev)), "gfn_kde_morton_keys")
-    perm = torch.argsort(keys, dim=1)
+    # one flat radix sort of (row << 16 | 16-bit key) instead of a segmented sort per row (80 merge launches, 0.7 ms at 32 x 20000)
+    if Bt < (1 << 15):
+        keys += torch.arange(Bt, device=dev, dtype=torch.int32)[:, None] << 16
+        perm = torch.sort(keys.reshape(-1), stable=True)[1].reshape(Bt, N) - (torch.arange(Bt, device=dev) * N)[:, None]
+    else:
+        perm = torch.argsort(keys, dim=1, stable=True)
     return torch.gather(pts, 1, perm[..., None].expand(Bt, N, 4)).contiguous(), perm
 
 

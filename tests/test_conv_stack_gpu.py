@@ -74,6 +74,19 @@ def test_conv_block_fp16_operands(B, C, M, G):
     assert err <= 4e-3 * max(mag, 1.0), (err, mag)
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_conv_block_large_grid_two_items_per_workgroup(variant):
+    """>= 16384 work items: the launcher gives every workgroup two consecutive tiles (pipelined back to back, zero
+    padding refreshed between them); the two-pass kernels are the bit-exact reference."""
+    from gfnet_amd import ops
+
+    B, C, G = 64, 8, 256
+    x, (w, cb, alpha, beta, pw, pb), _ = _block_case(B, C, C, G)
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    got = ops.conv_block(x, packed, C, variant=variant)
+    assert torch.equal(got, ops.conv_block(x, packed, C, variant=variant | 1))
+
+
 @pytest.mark.parametrize("B,M,K,G", [(3, 3, 24, 16), (2, 3, 417, 8), (1, 5, 7, 5), (1, 1, 3, 4)])
 def test_pointwise_conv_matches_torch(B, M, K, G):
     from gfnet_amd import ops
