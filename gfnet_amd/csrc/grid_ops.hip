@@ -161,6 +161,71 @@ __device__ __forceinline__ float interp_at(const float *pl, int H, int W, int Ho
            ly * (hx * pl[(size_t)y1 * W + x0] + lx * pl[(size_t)y1 * W + x1]);
 }
 
+// ---- image resize + normalise ----------------------------------------------------
+// ATen upsample_bicubic2d, align_corners=False: src = (dst+0.5)*in/out - 0.5 (not clamped), taps floor(src)-1 .. +2 with
+// clamped indices, cubic convolution coefficients with A = -0.75, rows first then columns.
+__device__ __forceinline__ float cubic1(float x) { return ((-0.75f + 2.f) * x - (-0.75f + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x) { return ((-0.75f * x - 5.f * -0.75f) * x + 8.f * -0.75f) * x - 4.f * -0.75f; }
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+    c[0] = cubic2(t + 1.f);
+    c[1] = cubic1(t);
+    c[2] = cubic1(1.f - t);
+    c[3] = cubic2(2.f - t);
+}
+
+struct NormParams {
+    float mean[3], std[3];
+};
+
+// in (B, >=3, H, W) with batch stride in_bs; out (B, 3, Ho, Wo) = (resize(in[:, :3]) - mean) / std.  One thread per output
+// pixel (the three channels share indices and coefficients).  mode 0 bilinear, 1 bicubic.
+__global__ __launch_bounds__(256) void resize_normalize_kernel(const float *__restrict__ in, long in_bs, float *__restrict__ out,
+                                                               int B, int H, int W, int Ho, int Wo, int mode, NormParams np) {
+    const long total = (long)B * Ho * Wo;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const bool same = H == Ho && W == Wo;  // transforms.Resize returns the image untouched
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wo);
+        const long t = idx / Wo;
+        const int y = (int)(t % Ho), b = (int)(t / Ho);
+        const float *src = in + (size_t)b * in_bs;
+        float v[3];
+        if (same) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = src[((size_t)c * H + y) * W + x];
+        } else if (mode == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = interp_at(src + (size_t)c * H * W, H, W, Ho, Wo, y, x);
+        } else {
+            const float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+            const float flx = floorf(fx), fly = floorf(fy);
+            const int ix = (int)flx, iy = (int)fly;
+            float cx[4], cy[4];
+            cubic_coeffs(fx - flx, cx);
+            cubic_coeffs(fy - fly, cy);
+            int xs[4], ys[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xs[i] = min(max(ix - 1 + i, 0), W - 1);
+                ys[i] = min(max(iy - 1 + i, 0), H - 1);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *pl = src + (size_t)c * H * W;
+                float rows[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float *r = pl + (size_t)ys[i] * W;
+                    rows[i] = r[xs[0]] * cx[0] + r[xs[1]] * cx[1] + r[xs[2]] * cx[2] + r[xs[3]] * cx[3];
+                }
+                v[c] = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(((size_t)b * 3 + c) * Ho + y) * Wo + x] = (v[c] - np.mean[c]) / np.std[c];
+    }
+}
+
 __global__ __launch_bounds__(256) void interp_bilinear_kernel(const float *__restrict__ in, float *__restrict__ out, int BC,
                                                               int H, int W, int Ho, int Wo) {
     const long total = (long)BC * Ho * Wo;
@@ -272,6 +337,23 @@ GFN_EXPORT int gfn_interp_bilinear_fwd(const float *in, float *out, int BC, int 
     hipLaunchKernelGGL(interp_bilinear_kernel, dim3(grid_for((long)BC * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in,
                        out, BC, H, W, Ho, Wo);
     return gfn::check_launch("interp_bilinear_kernel");
+}
+
+GFN_EXPORT int gfn_resize_normalize_fwd(const float *in, int64_t in_bs, float *out, int B, int H, int W, int Ho, int Wo, int mode,
+                                        const float *mean3, const float *std3, gfn_stream_t stream) {
+    if (!in || !out || !mean3 || !std3 || B < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || in_bs < 3L * H * W)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "resize_normalize: bad argument");
+    if (mode != 0 && mode != 1) return gfn::fail(GFN_ERR_INVALID_ARG, "resize_normalize: mode must be 0 (bilinear) or 1 (bicubic)");
+    NormParams np;
+    for (int c = 0; c < 3; ++c) {
+        if (!(std3[c] != 0.f)) return gfn::fail(GFN_ERR_INVALID_ARG, "resize_normalize: zero std");
+        np.mean[c] = mean3[c];
+        np.std[c] = std3[c];
+    }
+    if (B == 0) return GFN_OK;
+    hipLaunchKernelGGL(resize_normalize_kernel, dim3(grid_for((long)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, (long)in_bs,
+                       out, B, H, W, Ho, Wo, mode, np);
+    return gfn::check_launch("resize_normalize_kernel");
 }
 
 GFN_EXPORT int gfn_flow_update_fwd(float *flow, float *certainty, const float *delta, int64_t delta_bs, float *disp_prev,

@@ -1,0 +1,174 @@
+"""Evaluation harness -- the counterpart of the reference's test.py:57-75 loop and of
+benchmark/multimodal_homog_benchmark_multiscale.py:54-78, batched and sharded.
+
+Dataset layout (README.md:47-53, test.py:61-64, datasets/homography_dataset_large_size.py:113-119):
+
+    <root>/source/<name>.<ext>     source image
+    <root>/target/<name>.<ext>     target image (same file name)
+    <root>/H_s2t/<name>.json       {"H": [[..3x3..]]}  ground-truth homography source -> target
+
+The reference walks the pairs one by one (match -> sample -> cv2.findHomography -> corner error) and prints
+AUC@3/5/10/20, ACE and the mean runtime.  Here pairs are decoded on the host, grouped into batches of equal image
+size, and every batch runs match -> sample -> solve on the device in one go; with torch.distributed initialised the
+pairs are sharded over the ranks (parallel.shard_range) and the per-pair errors gathered at the end.
+
+The matcher is any object with the reference's surface:
+    match(im_a, im_b)                         # per pair (PIL images), as test.py uses it, or, preferred,
+    match_batch(im_a, im_b)                   # (B,3,H,W) float tensors in [0,1] on the GPU -> (warp, certainty)
+plus `sample` semantics through gfnet_amd.model.network.sample_batched.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import parallel
+from .estimation import auc, corner_error, estimate_homographies
+from .utils.image import to_tensor
+
+THRESHOLDS = (3, 5, 10, 20)
+
+
+def list_pairs(root, ext=None):
+    """[(source path, target path, H json path)] in sorted order.  `root` is the directory that holds source/,
+    target/ and H_s2t/ (test.py:61-64 derives the other two from the source path the same way)."""
+    src = os.path.join(root, "source")
+    if not os.path.isdir(src):
+        raise FileNotFoundError(f"{src}: expected <root>/source, <root>/target, <root>/H_s2t")
+    pairs = []
+    for name in sorted(os.listdir(src)):
+        stem, e = os.path.splitext(name)
+        if ext is not None and e.lstrip(".").lower() != ext.lower():
+            continue
+        tgt = os.path.join(root, "target", name)
+        hj = os.path.join(root, "H_s2t", stem + ".json")
+        if not os.path.isfile(tgt) or not os.path.isfile(hj):
+            raise FileNotFoundError(f"pair '{name}': missing {tgt if not os.path.isfile(tgt) else hj}")
+        pairs.append((os.path.join(src, name), tgt, hj))
+    return pairs
+
+
+def load_homography(path):
+    """H_s2t as float32, like estimation.py:52-53."""
+    with open(path, "r") as f:
+        return np.array(json.load(f)["H"], dtype=np.float32)
+
+
+def _load_image(path):
+    from PIL import Image
+
+    return to_tensor(Image.open(path).convert("RGB"))
+
+
+def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOLDS, ext=None, seed=0, progress=None):
+    """Run the whole test set.  Returns a dict: auc@t, ace (mean corner error), time (seconds per pair, device work
+    included), errors (per pair, dataset order), n.  Every rank returns the full result."""
+    from .model.network import sample_batched
+
+    pairs = list_pairs(root, ext)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    rank = torch.distributed.get_rank() if dist_on else 0
+    world = torch.distributed.get_world_size() if dist_on else 1
+    lo, hi = parallel.shard_range(len(pairs), rank, world)
+    mine = pairs[lo:hi]
+    errors = np.full(len(mine), np.nan, np.float64)
+    elapsed = 0.0
+    i = 0
+    while i < len(mine):
+        # a batch = consecutive pairs whose images have the same size (test sets are uniform; a change closes the batch)
+        ims_a, ims_b, Hs = [], [], []
+        while i + len(ims_a) < len(mine) and len(ims_a) < batch_size:
+            a, b, hj = mine[i + len(ims_a)]
+            ta, tb = _load_image(a), _load_image(b)
+            if ims_a and (ta.shape != ims_a[0].shape or tb.shape != ims_b[0].shape):
+                break
+            ims_a.append(ta)
+            ims_b.append(tb)
+            Hs.append(load_homography(hj))
+        n = len(ims_a)
+        h1, w1 = ims_a[0].shape[-2:]
+        h2, w2 = ims_b[0].shape[-2:]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        A, Bt = torch.stack(ims_a).cuda(non_blocking=True), torch.stack(ims_b).cuda(non_blocking=True)
+        with torch.inference_mode():
+            if hasattr(matcher, "match_batch"):
+                warp, cert = matcher.match_batch(A, Bt)
+                good, _ = sample_batched(matcher, warp, cert, num_samples)
+            else:  # the reference's per-pair surface
+                gs = []
+                for k in range(n):
+                    w_, c_ = matcher.match(A[k:k + 1], Bt[k:k + 1])
+                    gs.append(matcher.sample(w_, c_, num_samples)[0])
+                good = torch.stack(gs)
+            Hp = estimate_homographies(good, (w1, h1, w2, h2), seed=seed + lo + i).cpu().numpy()
+        torch.cuda.synchronize()
+        elapsed += time.perf_counter() - t0
+        for k in range(n):
+            errors[i + k] = corner_error(Hs[k], Hp[k], w1, h1)
+        i += n
+        if progress:
+            progress(lo + i, len(pairs))
+    all_err, total_time = _gather(errors, elapsed, len(pairs), lo, world)
+    res = {f"auc@{t}": v for t, v in zip(thresholds, auc(all_err, thresholds))}
+    res.update(ace=float(np.mean(all_err)), time=total_time / max(len(pairs), 1), errors=all_err, n=len(pairs))
+    return res
+
+
+def _gather(errors, elapsed, n_total, lo, world):
+    if world == 1:
+        return errors, elapsed
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = torch.zeros(n_total + 1, dtype=torch.float64, device=dev)
+    buf[lo:lo + len(errors)] = torch.from_numpy(errors).to(dev)
+    buf[n_total] = elapsed
+    dist.all_reduce(buf)  # disjoint slots: the sum is the concatenation; slot n_total sums the ranks' device time
+    out = buf.cpu().numpy()
+    return out[:n_total], float(out[n_total]) / world  # ranks run concurrently: wall time ~ mean of the ranks
+
+
+def main(argv=None):
+    """python -m gfnet_amd.evaluate --conf_path gfnet_configs/basic.json --root <dataset dir> --backbone module:factory
+    The backbone factory returns a callable (images (2B,3,H,W), upsample) -> (pyramid A, pyramid B) -- e.g. a wrapper
+    around the reference's GFNet.extract_features; weights are not part of this package."""
+    import argparse
+    import importlib
+
+    from .model.network import GFNet
+
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--conf_path", required=True)
+    ap.add_argument("--root", required=True, help="directory with source/ target/ H_s2t/")
+    ap.add_argument("--backbone", required=True, help="module:function returning the backbone callable")
+    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--ext", default=None)
+    ap.add_argument("--conv_precision", choices=("fp32", "fp16"), default="fp32")
+    ap.add_argument("--refiner_ckpt", default=None, help="torch checkpoint with a 'model' state_dict (conv_refiner.* entries are loaded)")
+    args = ap.parse_args(argv)
+    rank, world, _ = parallel.init_from_env()
+    with open(args.conf_path) as f:
+        conf = json.load(f)
+    mod, fn = args.backbone.split(":")
+    backbone = getattr(importlib.import_module(mod), fn)()
+    model = GFNet(conf, initial_res=(448, 448), upsample_res=(560, 560), symmetric=True, upsample_preds=True, attenuate_cert=True,
+                  backbone=backbone).cuda().eval()
+    if args.refiner_ckpt:
+        sd = torch.load(args.refiner_ckpt, map_location="cuda")["model"]
+        model.conv_refiner.load_state_dict({k[len("conv_refiner."):]: v for k, v in sd.items() if k.startswith("conv_refiner.")})
+    for r in model.conv_refiner.values():
+        r.conv_precision = args.conv_precision
+    res = evaluate(model, args.root, batch_size=args.batch_size, ext=args.ext)
+    if rank == 0:
+        name = os.path.basename(os.path.normpath(args.root))
+        print({f"{k}_{name}": v for k, v in res.items() if k.startswith("auc@")})
+        print(f"ACE: {res['ace']}")
+        print(f"Time: {res['time']}")
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -283,21 +283,42 @@ class GFNet(nn.Module):
     @torch.inference_mode()
     def match(self, im0, im1, *args, batched=True):
         """Same contract as the reference: paths / PIL images / tensors in, (warp, certainty) out.
-        Needs a backbone; image resize + ImageNet normalisation are done with torch."""
-        from ..utils.image import load_pair
+        Needs a backbone; image resize + ImageNet normalisation run in one HIP kernel with the
+        reference's interpolation modes (network.py:293-346: bilinear for path inputs and for the upsample pass,
+        bicubic for PIL / tensor inputs, no antialiasing)."""
+        from ..utils.image import load_pair, resize_normalise
 
-        im_a, im_b, batched = load_pair(im0, im1, batched)
-        dev = torch.device("cuda")
+        im_a, im_b, batched, mode = load_pair(im0, im1, batched)
+        im_a, im_b = im_a.cuda(), im_b.cuda()
 
         def pyramids(res, upsample):
-            a, b = (t.to(dev) for t in _resize_normalise(im_a, im_b, res))
-            return self.extract_features(torch.cat([a, b]), upsample)
+            m = "bilinear" if upsample else mode
+            return self.extract_features(torch.cat([resize_normalise(im_a, res, m), resize_normalise(im_b, res, m)]), upsample)
 
         p0, p1 = pyramids((self.h_resized, self.w_resized), False)
         u0 = u1 = None
         if self.upsample_preds:
             u0, u1 = pyramids(self.upsample_res, True)
         return self.match_pyramids(p0, p1, u0, u1, batched=batched)
+
+    @torch.inference_mode()
+    def match_batch(self, im_a, im_b, mode="bicubic"):
+        """match() for B pairs at once: im_a, im_b (B,3+,H,W) float tensors in [0,1] (what ToTensor gives for the PIL
+        images test.py passes, hence the bicubic first pass; the upsample pass is bilinear as in network.py:342-344).
+        Returns warp (B,G,2G,4) and certainty (B,G,2G)."""
+        from ..utils.image import resize_normalise
+
+        im_a, im_b = im_a.cuda(), im_b.cuda()
+
+        def pyramids(res, upsample):
+            m = "bilinear" if upsample else mode
+            return self.extract_features(torch.cat([resize_normalise(im_a, res, m), resize_normalise(im_b, res, m)]), upsample)
+
+        p0, p1 = pyramids((self.h_resized, self.w_resized), False)
+        u0 = u1 = None
+        if self.upsample_preds:
+            u0, u1 = pyramids(self.upsample_res, True)
+        return self.match_pyramids(p0, p1, u0, u1, batched=True)
 
     # ---- sample (network.py:385-414) --------------------------------------------------------------------
     def sample(self, matches, certainty, num=5_000):
@@ -341,7 +362,3 @@ def sample_batched(model, warp, certainty, num=5_000):
     return torch.gather(gm, 1, bal[..., None].expand(B, n2, 4)).contiguous(), torch.gather(gc, 1, bal)
 
 
-def _resize_normalise(im_a, im_b, res):
-    from ..utils.image import resize_normalise
-
-    return resize_normalise(im_a, res), resize_normalise(im_b, res)

@@ -297,6 +297,31 @@ def homography_dlt(pts, weight=None):
     return H, ok
 
 
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def resize_normalise(im, size, mode="bicubic", mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """get_tuple_transform_ops(resize=size, mode, normalize=True) of the reference (utils/utils.py:18-27) on a
+    (B,>=3,H,W) float image batch in [0,1]: F.interpolate(mode, align_corners=False, antialias=False) + (x-mean)/std on
+    the first three channels, one HIP kernel.  mode: 'bicubic' or 'bilinear' (the reference's mode=2)."""
+    import ctypes
+
+    dev = require_gpu(im)
+    if im.dim() != 4 or im.shape[1] < 3:
+        raise ValueError("resize_normalise: expected (B, >=3, H, W)")
+    if mode not in ("bilinear", "bicubic"):
+        raise ValueError("resize_normalise: mode must be 'bilinear' or 'bicubic'")
+    x = f32c(im)
+    B, C, H, W = x.shape
+    Ho, Wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    out = torch.empty((B, 3, Ho, Wo), device=dev, dtype=torch.float32)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(_L().gfn_resize_normalize_fwd(ptr(x), C * H * W, ptr(out), B, H, W, Ho, Wo, 1 if mode == "bicubic" else 0, m3, s3,
+                                        stream_ptr(dev)), "gfn_resize_normalize_fwd")
+    return out
+
+
 def conv_block_pack(dw_w, dw_b, bn_alpha, bn_beta, pw_w, pw_b):
     """Pack one ConvRefiner block (model/network.py:471-487) for conv_block: dw_w (C,25) or (C,1,5,5),
     dw_b (C) or None, eval-mode BatchNorm as y = x*alpha + beta, pw_w (M,C[,1,1]), pw_b (M)."""

@@ -194,6 +194,18 @@ int gfn_homography_ransac(const float *pts, int Bt, int N, double thresh, int it
 int gfn_homography_dlt(const float *pts, const float *weight, int Bt, int N, double *H, int *ok, gfn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image resize + normalise in front of the backbone -- GFNet.match's
+ * get_tuple_transform_ops(resize, mode, normalize=True), model/network.py:293-346 with utils/utils.py:18-27,
+ * 87-116: torchvision Resize on a float tensor with antialias=None (= F.interpolate(mode,
+ * align_corners=False), no antialiasing) followed by Normalize on the first three channels.
+ *   in (B, >=3, H, W) floats in [0,1], batch stride in_bs floats; out (B,3,Ho,Wo) = (resize(in[:, :3]) - mean) / std;
+ *   mode 0 = bilinear (the reference's mode=2: path inputs and the upsample pass), 1 = bicubic (PIL / tensor
+ *   inputs); mean3 / std3: three host floats each (ImageNet statistics in the reference).
+ */
+int gfn_resize_normalize_fwd(const float *in, int64_t in_bs, float *out, int B, int H, int W, int Ho, int Wo, int mode,
+                             const float *mean3, const float *std3, gfn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Refiner conv stack -- ConvRefiner.create_block / forward, model/network.py:471-487
  * and :560-563: nine blocks of depthwise 5x5 conv -> BatchNorm2d(eval) -> ReLU -> 1x1 conv, then a
  * final 1x1 conv to 3 channels.  Depthwise, norm and accumulation always fp32; the 1x1 products fp32

@@ -165,6 +165,35 @@ def interpolate_bilinear(x, size, variant="f32"):
     return out
 
 
+def interpolate_bicubic(x, size, variant="f32"):
+    """F.interpolate(x, size=size, mode='bicubic', align_corners=False, antialias=False)."""
+    x = _f32(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (size, size) if np.isscalar(size) else size
+    out = np.empty((B, C, Ho, Wo), _real(variant))
+    lib(variant).oracle_interp_bicubic(_p(x), _p(out), _c_int(B * C), _c_int(H), _c_int(W), _c_int(Ho), _c_int(Wo))
+    return out
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def resize_normalise(im, size, mode="bicubic", variant="f32"):
+    """get_tuple_transform_ops(resize=size, mode, normalize=True) on a (B,3+,H,W) float image in [0,1] --
+    utils/utils.py:18-27, 87-116 as GFNet.match calls it (model/network.py:293-346): torchvision Resize on a tensor with
+    antialias=None = F.interpolate(mode, align_corners=False, antialias=False); mode 'bilinear' for path inputs and the
+    upsample pass (the reference passes mode=2), 'bicubic' (the default) for PIL / tensor inputs; then (x - mean) / std
+    on the first three channels."""
+    x = _f32(im)[:, :3]
+    f = {"bicubic": interpolate_bicubic, "bilinear": interpolate_bilinear}[mode]
+    y = f(x, size, variant) if tuple(x.shape[-2:]) != tuple(size) else x.astype(_real(variant))
+    rt = _real(variant)
+    mean = np.asarray(IMAGENET_MEAN, rt).reshape(1, 3, 1, 1)
+    std = np.asarray(IMAGENET_STD, rt).reshape(1, 3, 1, 1)
+    return ((y - mean) / std).astype(rt)
+
+
 def _linspace_f32(start, end, steps):
     """torch.linspace in float32 (ATen: symmetric fill from both ends)."""
     start, end = np.float32(start), np.float32(end)

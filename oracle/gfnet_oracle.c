@@ -277,3 +277,44 @@ EXPORT void oracle_interp_bilinear(const float *in, real *out, int BC, int H, in
             }
         }
 }
+
+/* F.interpolate(x, size=(Ho,Wo), mode='bicubic', align_corners=False, antialias=False) -- what torchvision's
+ * transforms.Resize does to the [0,1] float tensors of GFNet.match (model/network.py:299-346, utils/utils.py:87-92).
+ * ATen upsample_bicubic2d: src = (dst+0.5)*in/out - 0.5 (not clamped), i = floor(src), t = src - i, taps i-1..i+2 with
+ * indices clamped to the image, cubic convolution coefficients with A = -0.75, rows first then columns. */
+static real cubic1(real x, real A) { return ((A + 2) * x - (A + 3)) * x * x + 1; }
+static real cubic2(real x, real A) { return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A; }
+static void cubic_coeffs(real t, real c[4]) {
+    const real A = (real)-0.75;
+    c[0] = cubic2(t + 1, A);
+    c[1] = cubic1(t, A);
+    c[2] = cubic1(1 - t, A);
+    c[3] = cubic2(2 - t, A);
+}
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+EXPORT void oracle_interp_bicubic(const float *in, real *out, int BC, int H, int W, int Ho, int Wo) {
+    const real sy = (real)H / (real)Ho, sx = (real)W / (real)Wo;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < BC; ++p)
+        for (int y = 0; y < Ho; ++y) {
+            const real fy = ((real)y + (real)0.5) * sy - (real)0.5;
+            const int iy = (int)floor((double)fy);
+            real cy[4];
+            cubic_coeffs(fy - (real)iy, cy);
+            for (int x = 0; x < Wo; ++x) {
+                const real fx = ((real)x + (real)0.5) * sx - (real)0.5;
+                const int ix = (int)floor((double)fx);
+                real cx[4];
+                cubic_coeffs(fx - (real)ix, cx);
+                const float *s = in + (size_t)p * H * W;
+                real rows[4];
+                for (int i = 0; i < 4; ++i) {
+                    const float *r = s + (size_t)clampi(iy - 1 + i, 0, H - 1) * W;
+                    rows[i] = (real)r[clampi(ix - 1, 0, W - 1)] * cx[0] + (real)r[clampi(ix, 0, W - 1)] * cx[1] +
+                              (real)r[clampi(ix + 1, 0, W - 1)] * cx[2] + (real)r[clampi(ix + 2, 0, W - 1)] * cx[3];
+                }
+                out[((size_t)p * Ho + y) * Wo + x] = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+            }
+        }
+}

@@ -414,10 +414,53 @@ def g8_estimation(cv2_stub):
     save("g8_estimation", **arrays)
 
 
+def g9_resize_normalise():
+    """N3: the image transform GFNet.match applies (model/network.py:293-346) through the reference's own
+    utils.utils.get_tuple_transform_ops.  torchvision is absent, so its two tensor-branch calls are restated in the stub:
+    transforms.Resize(size, mode, antialias=None) on a float tensor = F.interpolate(mode, align_corners=False,
+    antialias=False) with the int -> mode table of torchvision (2 = bilinear, 3 = bicubic), transforms.Normalize =
+    (x - mean) / std.  Inputs: synth lattices in [0,1]; sizes cover up-/down-scaling and the identity."""
+    import utils.utils as ru
+    import torchvision.transforms as tvt
+
+    class Resize:
+        def __init__(self, size, interpolation=3, antialias=None):
+            self.size = size
+            self.mode = {2: "bilinear", 3: "bicubic"}[int(getattr(interpolation, "value", interpolation))]
+
+        def __call__(self, im):
+            return F.interpolate(im[None], size=self.size, mode=self.mode, align_corners=False, antialias=False)[0]
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+
+        def __call__(self, im):
+            return (im - self.mean) / self.std
+
+    tvt.Resize, tvt.Normalize = Resize, Normalize
+    ru.transforms.Resize, ru.transforms.Normalize = Resize, Normalize
+    arrays = {}
+    cases = [("down", (61, 83), (28, 42)), ("up", (24, 20), (56, 70)), ("same", (28, 28), (28, 28)), ("mixed", (50, 30), (42, 42))]
+    for i, (name, (H, W), size) in enumerate(cases):
+        a = (synth.lattice_uniform((3, H, W), 900 + i) * 0.5 + 0.5).astype(np.float32)
+        b = (synth.lattice_uniform((3, H, W), 950 + i) * 0.5 + 0.5).astype(np.float32)
+        arrays[f"{name}.seed"] = np.array([900 + i, 950 + i, H, W, size[0], size[1]])
+        for mode_name, mode in (("bicubic", 3), ("bilinear", 2)):
+            ops = ru.get_tuple_transform_ops(resize=size, mode=mode, normalize=True)
+            oa, ob = ops((torch.from_numpy(a), torch.from_numpy(b)))
+            arrays[f"{name}.{mode_name}.a"] = oa.numpy()
+            arrays[f"{name}.{mode_name}.b"] = ob.numpy()
+    save("g9_resize_normalise", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     cv2_stub = install_stubs()
     sys.path.insert(0, REF)
+    if sys.argv[1:] == ["g9"]:  # add one fixture without touching the others
+        g9_resize_normalise()
+        return
     from utils.local_correlation import local_correlation
     from utils.kde import kde
     import model.network as network
@@ -430,6 +473,7 @@ def main():
     g6_match_post(network)
     g7_sample(network)
     g8_estimation(cv2_stub)
+    g9_resize_normalise()
     meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "KN-Zhang/GFNet snapshot 2026-01-28",
             "generator": "tests/golden/make_golden.py", "device": "cpu", "dtype": "float32"}
     with open(os.path.join(OUT, "meta.json"), "w") as f:

@@ -1,0 +1,172 @@
+"""Evaluation harness (gfnet_amd/evaluate.py): dataset layout of the reference (README.md:47-53,
+test.py:61-64), batched match -> sample -> solve, AUC/ACE bookkeeping, error gathering across ranks."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_dataset(root, homographies, sizes, ext="png"):
+    from PIL import Image
+
+    for d in ("source", "target", "H_s2t"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    rng = np.random.default_rng(3)
+    for i, (H, (w, h)) in enumerate(zip(homographies, sizes)):
+        name = f"pair_{i:03d}"
+        for d in ("source", "target"):
+            Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, d, f"{name}.{ext}"))
+        with open(os.path.join(root, "H_s2t", name + ".json"), "w") as f:
+            json.dump({"H": np.asarray(H).tolist()}, f)
+
+
+def _homographies(n, size, seed=5, corner=0.12):
+    """Random 4-corner perturbations (datasets/generate_random_H_large_size.py style), as 3x3 matrices."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        src = np.array([[0, 0], [size - 1, 0], [size - 1, size - 1], [0, size - 1]], np.float64)
+        dst = src + rng.uniform(-corner, corner, (4, 2)) * size
+        A = []
+        for (x, y), (u, v) in zip(src, dst):
+            A.append([x, y, 1, 0, 0, 0, -u * x, -u * y, -u])
+            A.append([0, 0, 0, x, y, 1, -v * x, -v * y, -v])
+        h = np.linalg.svd(np.asarray(A))[2][-1]
+        out.append((h / h[8]).reshape(3, 3))
+    return out
+
+
+def test_list_pairs_follows_the_reference_layout(tmp_path):
+    from gfnet_amd import evaluate
+
+    Hs = _homographies(3, 32)
+    _write_dataset(str(tmp_path), Hs, [(32, 32)] * 3, ext="jpg")
+    pairs = evaluate.list_pairs(str(tmp_path))
+    assert [os.path.basename(p[0]) for p in pairs] == ["pair_000.jpg", "pair_001.jpg", "pair_002.jpg"]
+    assert all(p[1].endswith(os.path.join("target", os.path.basename(p[0]))) for p in pairs)
+    assert pairs[1][2].endswith(os.path.join("H_s2t", "pair_001.json"))
+    np.testing.assert_allclose(evaluate.load_homography(pairs[2][2]), np.asarray(Hs[2], np.float32))
+    assert evaluate.list_pairs(str(tmp_path), ext="png") == []
+    os.remove(pairs[0][2])
+    with pytest.raises(FileNotFoundError):
+        evaluate.list_pairs(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        evaluate.list_pairs(str(tmp_path / "nowhere"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from gfnet_amd import evaluate, parallel
+
+    parallel.init_from_env(backend="gloo")
+    lo, hi = parallel.shard_range(n, rank, world)
+    errs, t = evaluate._gather(np.arange(lo, hi, dtype=np.float64) * 0.5, 1.0 + rank, n, lo, world)
+    q.put((rank, errs, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_error_gather_world2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, errs, t in res:
+        np.testing.assert_array_equal(errs, np.arange(7) * 0.5)
+        assert t == pytest.approx(1.5)
+
+
+class _OracleMatcher:
+    """Stands in for a trained GFNet: returns the dense warp of the ground-truth homography (what match() converges
+    to), so that everything after match -- sampling, coordinate conventions, solve, errors -- is what is tested."""
+    sample_mode = "threshold_balanced"
+    sample_thresh = 0.05
+
+    def __init__(self, Hs, G=64):
+        self.Hs, self.G, self.calls = Hs, G, []
+
+    def match_batch(self, A, B):
+        n, _, h, w = A.shape
+        k0 = sum(self.calls)
+        self.calls.append(n)
+        G = self.G
+        lin = (torch.arange(G, dtype=torch.float64) * 2 + 1) / G - 1
+        gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+        px, py = (w - 1) * (gx + 1) / 2, (h - 1) * (gy + 1) / 2
+        warps = []
+        for k in range(n):
+            H = torch.from_numpy(np.asarray(self.Hs[k0 + k], np.float64))
+            den = H[2, 0] * px + H[2, 1] * py + H[2, 2]
+            u = (H[0, 0] * px + H[0, 1] * py + H[0, 2]) / den
+            v = (H[1, 0] * px + H[1, 1] * py + H[1, 2]) / den
+            warps.append(torch.stack((gx, gy, 2 * u / (w - 1) - 1, 2 * v / (h - 1) - 1), -1))
+        warp = torch.stack(warps).float().cuda()
+        inside = ((warp[..., 2:].abs() <= 1).all(-1)).float()
+        return warp, inside * 0.9 + 0.01
+
+
+@pytest.mark.gpu
+def test_evaluate_recovers_known_homographies(tmp_path):
+    from gfnet_amd import evaluate
+
+    sizes = [(96, 96)] * 5 + [(80, 64)] * 2          # a size change closes a batch
+    Hs = _homographies(7, 64, corner=0.08)
+    _write_dataset(str(tmp_path), Hs, sizes)
+    m = _OracleMatcher(Hs)
+    seen = []
+    res = evaluate.evaluate(m, str(tmp_path), batch_size=4, num_samples=2000, progress=lambda i, n: seen.append((i, n)))
+    assert m.calls == [4, 1, 2]
+    assert seen[-1] == (7, 7) and res["n"] == 7 and res["errors"].shape == (7,)
+    assert np.all(res["errors"] < 1e-2), res["errors"]   # px: exact correspondences, fp32 coordinates
+    assert res["ace"] == pytest.approx(float(np.mean(res["errors"])))
+    assert all(res[f"auc@{t}"] > 0.99 for t in (3, 5, 10, 20))
+    assert res["time"] > 0
+
+
+@pytest.mark.gpu
+def test_match_batch_resizes_and_calls_the_backbone():
+    """GFNet.match_batch: resize + normalise per pass (448 bicubic, 560 bilinear), backbone on cat(A, B)."""
+    from gfnet_amd.model.network import GFNet
+    from gfnet_amd import ops
+    import oracle
+
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def backbone(x, upsample):
+        calls.append((tuple(x.shape), bool(upsample), x.clone()))
+        raise Stop
+
+    conf = {"matcher": {"num_grid": [32, 32, 64, 128, 256], "radius": [7, 6, 4, 2, 0], "num_itr": [1, 1, 1, 1, 1],
+                        "displacement_dim": [64, 64, 32, 16, 8]}, "encoder_cfg": {"feat_chs": [64, 32, 16, 8]}}
+    model = GFNet(conf, symmetric=True, upsample_preds=True, attenuate_cert=True, backbone=backbone).cuda().eval()
+    a = torch.rand(2, 3, 50, 70)
+    b = torch.rand(2, 3, 50, 70)
+    with pytest.raises(Stop):
+        model.match_batch(a, b)
+    shape, up, x = calls[0]
+    assert shape == (4, 3, 448, 448) and up is False
+    want = oracle.resize_normalise(torch.cat((a, b)).numpy(), (448, 448), "bicubic")
+    np.testing.assert_allclose(x.cpu().numpy(), want, atol=2e-5)

@@ -293,3 +293,36 @@ def test_kde_culled_equals_dense_and_oracle_on_match_like_points():
     y = np.ascontiguousarray(x[:, ::8])
     c2 = host(ops.kde_density(dev(x), dev(y), std=0.1, cull=True))
     np.testing.assert_allclose(c2[0], oracle.kde(x[0], 0.1, half=False, down=8), rtol=1e-4)
+
+
+# ---- N3 image resize + normalise ----------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["down", "up", "same", "mixed"])
+def test_g9_resize_normalise_hip(case):
+    from gfnet_amd import ops
+
+    g = load_golden("g9_resize_normalise")
+    sa, sb, H, W, h, w = (int(v) for v in g[f"{case}.seed"])
+    a = (synth.lattice_uniform((3, H, W), sa) * 0.5 + 0.5).astype(np.float32)
+    b = (synth.lattice_uniform((3, H, W), sb) * 0.5 + 0.5).astype(np.float32)
+    x = np.stack((a, b))
+    for mode in ("bicubic", "bilinear"):
+        got = host(ops.resize_normalise(dev(x), (h, w), mode))
+        assert_close(got[0], g[f"{case}.{mode}.a"], 1e-5, f"{case} {mode} a")
+        assert_close(got[1], g[f"{case}.{mode}.b"], 1e-5, f"{case} {mode} b")
+        assert_close(got, oracle.resize_normalise(x, (h, w), mode), 1e-5, "vs oracle")
+
+
+def test_resize_normalise_image_sizes_and_extra_channel():
+    """448 / 560 targets from an odd-sized RGBA-like tensor (the 4th channel is ignored, utils/utils.py:110-114)."""
+    from gfnet_amd import ops
+    from gfnet_amd._lib import GfnError
+
+    x = (synth.lattice_uniform((1, 4, 301, 517), 77) * 0.5 + 0.5).astype(np.float32)
+    for size, mode in (((448, 448), "bicubic"), ((560, 560), "bilinear")):
+        got = host(ops.resize_normalise(dev(x), size, mode))
+        assert got.shape == (1, 3) + size
+        assert_close(got, oracle.resize_normalise(x, size, mode), 1e-5, f"{size} {mode}")
+    with pytest.raises(ValueError):
+        ops.resize_normalise(dev(x), (8, 8), "nearest")
+    with pytest.raises(ValueError):
+        ops.resize_normalise(dev(x[:, :2]), (8, 8))

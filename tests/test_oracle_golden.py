@@ -224,3 +224,19 @@ def test_g8_demo_estimation_ace():
             assert np.isnan(ace)
         else:
             assert abs(ace - ref) < 1e-9 * max(1, abs(ref)), (tag, ace, ref)
+
+
+# ---- G9: image resize + normalise in front of the backbone ----------------------
+@pytest.mark.parametrize("case", ["down", "up", "same", "mixed"])
+def test_g9_resize_normalise(case):
+    """oracle.resize_normalise against the reference's get_tuple_transform_ops (utils/utils.py:18-27) on synth images."""
+    import synth
+
+    g = load_golden("g9_resize_normalise")
+    sa, sb, H, W, h, w = (int(v) for v in g[f"{case}.seed"])
+    a = (synth.lattice_uniform((3, H, W), sa) * 0.5 + 0.5).astype(np.float32)
+    b = (synth.lattice_uniform((3, H, W), sb) * 0.5 + 0.5).astype(np.float32)
+    for mode in ("bicubic", "bilinear"):
+        got = oracle.resize_normalise(np.stack((a, b)), (h, w), mode)
+        assert_close(got[0], g[f"{case}.{mode}.a"], 1e-5, f"{case} {mode} a")
+        assert_close(got[1], g[f"{case}.{mode}.b"], 1e-5, f"{case} {mode} b")
