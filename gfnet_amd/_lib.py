@@ -38,6 +38,7 @@ _SIGNATURES = {
     "gfn_homography_ransac": [c_vp, c_int, c_int, c_double, c_int, ctypes.c_uint64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_i64, c_vp],
     "gfn_homography_dlt": [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
+    "gfn_local_corr_bwd_f0": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp],
     "gfn_resize_normalize_fwd": [c_vp, c_i64, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp],
     "gfn_conv_block_pack": [c_vp] * 7 + [c_int] * 2 + [c_vp],
     "gfn_conv_block_fwd": [c_vp] * 4 + [c_int] * 5 + [c_vp],

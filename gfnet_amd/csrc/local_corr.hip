@@ -163,6 +163,74 @@ __global__ __launch_bounds__(256) void local_corr_general_kernel(LcParams p) {
     }
 }
 
+// ---- backward w.r.t. feature0 ---------------------------------------------------
+// out[b,k,i,j] = sum_c (f0[b,c,i,j] / sqrt(c)) * S_c(k) with S_c(k) the bilinear sample of f1[b,c] at tap k; the reference
+// lets gradients reach feature0 only (local_correlation.py:54-60: the sampling runs under no_grad).  Hence
+//   grad_f0[b,c,i,j] = (sum_k grad_out[b,k,i,j] * S_c(k)) / sqrt(c):
+// one thread per (cell, 8-channel group) walks the K taps with the forward's own coordinate arithmetic.
+constexpr int kBwdCh = 8;
+__global__ __launch_bounds__(256) void local_corr_bwd_f0_kernel(LcParams p, const float *__restrict__ gout, long gout_bs,
+                                                                float *__restrict__ gf0, long gf0_bs) {
+    const int D = 2 * p.r + 1, K = D * D;
+    const int groups = (p.C + kBwdCh - 1) / kBwdCh;
+    const long total = (long)p.B * groups * p.G * p.G;
+    float ylo, yhi, xlo, xhi;
+    if (p.grid_based) {
+        ylo = (float)(-2.0 * p.r / p.G); yhi = (float)(2.0 * p.r / p.G);
+        xlo = ylo; xhi = yhi;
+    } else {
+        ylo = (float)(-2.0 * p.r / p.win_h); yhi = (float)(2.0 * p.r / p.win_h);
+        xlo = (float)(-2.0 * p.r / p.win_w); xhi = (float)(2.0 * p.r / p.win_w);
+    }
+    const size_t plane = (size_t)p.H * p.W, cs = (size_t)p.G * p.G;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % p.G);
+        long t = idx / p.G;
+        const int i = (int)(t % p.G);
+        t /= p.G;
+        const int cg = (int)(t % groups);
+        const int b = (int)(t / groups);
+        const int c0 = cg * kBwdCh, nc = min(kBwdCh, p.C - c0);
+        float nx, ny;
+        cell_coords(p, b, i, j, nx, ny);
+        const float *f1p = f1_of(p, b) + (size_t)c0 * plane;
+        const float *g = gout + (size_t)b * gout_bs + (size_t)i * p.G + j;
+        float acc[kBwdCh];
+#pragma unroll
+        for (int c = 0; c < kBwdCh; ++c) acc[c] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int ky = k / D, kx = k - ky * D;
+            const float gx = nx + gfn::linspace_at(xlo, xhi, D, kx);
+            const float gy = ny + gfn::linspace_at(ylo, yhi, D, ky);
+            const float ix = unnorm(gx, p.W), iy = unnorm(gy, p.H);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const bool sane = (fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f);
+            const int x0 = sane ? (int)fx : -4, y0 = sane ? (int)fy : -4;
+            const float w00 = (fx + 1.f - ix) * (fy + 1.f - iy), w01 = (ix - fx) * (fy + 1.f - iy);
+            const float w10 = (fx + 1.f - ix) * (iy - fy), w11 = (ix - fx) * (iy - fy);
+            const bool xa = (unsigned)x0 < (unsigned)p.W, xb = (unsigned)(x0 + 1) < (unsigned)p.W;
+            const bool ya = (unsigned)y0 < (unsigned)p.H, yb = (unsigned)(y0 + 1) < (unsigned)p.H;
+            const long o00 = (long)y0 * p.W + x0;
+            const float gk = g[(size_t)k * cs];
+#pragma unroll
+            for (int c = 0; c < kBwdCh; ++c) {
+                if (c >= nc) break;
+                const float *pl = f1p + c * plane;
+                float sv = 0.f;
+                if (ya & xa) sv += pl[o00] * w00;
+                if (ya & xb) sv += pl[o00 + 1] * w01;
+                if (yb & xa) sv += pl[o00 + p.W] * w10;
+                if (yb & xb) sv += pl[o00 + p.W + 1] * w11;
+                acc[c] = fmaf(gk, sv, acc[c]);
+            }
+        }
+        float *dst = gf0 + (size_t)b * gf0_bs + (size_t)c0 * cs + (size_t)i * p.G + j;
+#pragma unroll
+        for (int c = 0; c < kBwdCh; ++c)
+            if (c < nc) dst[c * cs] = acc[c] / p.sqrt_c;
+    }
+}
+
 // ---- fast tiled kernel -----------------------------------------------------------------------
 // Stage traffic: wave-iteration wi covers channel group (wi & 3) of the 64 region pixels starting
 // at (wi >> 2) * 64: four coalesced row-segment loads (one per channel) and one 16-byte LDS write
@@ -713,6 +781,34 @@ GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f
                                   gfn_stream_t stream) {
     return gfn_local_corr_fwd_ex(f0, f0_bs, f1, f1_second, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0,
                                  scratch, scratch_bytes, stream);
+}
+
+GFN_EXPORT int gfn_local_corr_bwd_f0(const float *grad_out, int64_t grad_out_bs, const float *f1, const float *f1_second,
+                                    const float *flow, float *grad_f0, int64_t grad_f0_bs, int B, int C, int G, int H, int W, int r,
+                                    int grid_based, int win_h, int win_w, gfn_stream_t stream) {
+    if (!grad_out || !f1 || !grad_f0) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: null tensor pointer");
+    if (f1_second && (B & 1)) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: symmetric batch must be even");
+    if (B < 0 || C <= 0 || G <= 0 || H <= 0 || W <= 0 || r < 0 || win_h <= 0 || win_w <= 0)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: bad size B=%d C=%d G=%d H=%d W=%d r=%d", B, C, G, H, W, r);
+    const long K = (long)(2 * r + 1) * (2 * r + 1);
+    if (grad_f0_bs < (long)C * G * G || grad_out_bs < K * G * G)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: batch stride smaller than one batch element");
+    if (!flow && !(G == win_h && G == win_w))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: flow=NULL needs num_grid == h == w");
+    if ((long)C * H * W >= (1L << 31)) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr_bwd: tensor too large");
+    if (B == 0) return GFN_OK;
+    LcParams p{};
+    p.f1 = f1; p.f1_second = f1_second; p.flow = flow;
+    p.Bh = f1_second ? B / 2 : B;
+    p.B = B; p.C = C; p.G = G; p.H = H; p.W = W;
+    p.sqrt_c = (float)sqrt((double)C);
+    p.inv_sqrt_c = (float)(1.0 / sqrt((double)C));
+    p.r = r; p.win_h = win_h; p.win_w = win_w; p.grid_based = grid_based;
+    const long total = (long)B * ((C + kBwdCh - 1) / kBwdCh) * G * G;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(local_corr_bwd_f0_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, grad_out, (long)grad_out_bs, grad_f0,
+                       (long)grad_f0_bs);
+    return gfn::check_launch("local_corr_bwd_f0_kernel");
 }
 
 namespace {

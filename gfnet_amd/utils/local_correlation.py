@@ -29,8 +29,18 @@ def local_correlation(featuremap_size, feature0, feature1, local_radius, num_gri
     num_grid, num_grid) with dtype/device of feature0; `im_A_coords` is accepted and ignored.
     Extra keyword `out`: a (B, K*num_level, G, G) fp32 view to write into (e.g. the channel slice
     of the refiner's concat buffer); it must have contiguous (K,G,G) planes.
-    Forward only: like the reference's sampling step this runs without autograd.
+    Gradients: like the reference (local_correlation.py:54-60, sampling under no_grad) only feature0
+    receives one; it is computed by gfn_local_corr_bwd_f0 when feature0.requires_grad (and `out` is None).
     """
+    if out is None and torch.is_grad_enabled() and feature0.requires_grad:
+        return _LocalCorrelationFn.apply(feature0, feature1, flow, tuple(int(v) for v in featuremap_size), int(local_radius),
+                                         int(num_grid), bool(grid_based_correlation), int(num_level))
+    return _forward(featuremap_size, feature0, feature1, local_radius, num_grid, padding_mode, flow, sample_mode,
+                    grid_based_correlation, num_level, out, _variant)
+
+
+def _forward(featuremap_size, feature0, feature1, local_radius, num_grid, padding_mode, flow, sample_mode,
+             grid_based_correlation, num_level, out, _variant):
     if padding_mode != "zeros" or sample_mode != "bilinear":
         raise ValueError("only padding_mode='zeros', sample_mode='bilinear' (the reference's settings) are supported")
     B, c, h, w = [int(v) for v in featuremap_size]
@@ -77,3 +87,46 @@ def local_correlation(featuremap_size, feature0, feature1, local_radius, num_gri
     if out is None and ret_dtype != torch.float32:
         res = res.to(ret_dtype)
     return res
+
+
+def _pyramid(f1, B, c, h, w, num_level, dev):
+    """feature1 and its 2x average-pooled levels (local_correlation.py:71), as the forward builds them."""
+    L = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    levels, hh, ww = [(f1, h, w)], h, w
+    for _ in range(1, num_level):
+        pooled = torch.empty((B, c, hh // 2, ww // 2), device=dev, dtype=torch.float32)
+        _lib.check(L.gfn_avg_pool2(_lib.ptr(f1), _lib.ptr(pooled), B * c, hh, ww, st), "gfn_avg_pool2")
+        f1, hh, ww = pooled, hh // 2, ww // 2
+        levels.append((f1, hh, ww))
+    return levels
+
+
+class _LocalCorrelationFn(torch.autograd.Function):
+    """local_correlation with the reference's gradient: d/d feature0 only."""
+
+    @staticmethod
+    def forward(ctx, feature0, feature1, flow, featuremap_size, r, G, grid_based, num_level):
+        res = _forward(featuremap_size, feature0, feature1, r, G, "zeros", flow, "bilinear", grid_based, num_level, None, 0)
+        ctx.save_for_backward(feature1, flow if flow is not None else torch.empty(0, device=feature0.device))
+        ctx.meta = (featuremap_size, r, G, grid_based, num_level, flow is not None, feature0.dtype)
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feature1, flow = ctx.saved_tensors
+        (B, c, h, w), r, G, grid_based, num_level, has_flow, dtype = ctx.meta
+        dev = grad_out.device
+        K1 = (2 * r + 1) ** 2
+        g = _lib.f32c(grad_out)
+        fl = _lib.f32c(flow) if has_flow else None
+        L = _lib.lib()
+        st = _lib.stream_ptr(dev)
+        total = None
+        for level, (f1, hh, ww) in enumerate(_pyramid(_lib.f32c(feature1), B, c, h, w, num_level, dev)):
+            gl = g[:, level * K1:(level + 1) * K1]
+            gf0 = torch.empty((B, c, G, G), device=dev, dtype=torch.float32)
+            _lib.check(L.gfn_local_corr_bwd_f0(_lib.c_vp(gl.data_ptr()), g.stride(0), _lib.ptr(f1), None, _lib.ptr(fl), _lib.ptr(gf0),
+                                               c * G * G, B, c, G, hh, ww, r, 1 if grid_based else 0, h, w, st), "gfn_local_corr_bwd_f0")
+            total = gf0 if total is None else total + gf0
+        return total.to(dtype), None, None, None, None, None, None, None

@@ -79,6 +79,14 @@ int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const
                           float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                           int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
+/* Backward of gfn_local_corr_fwd with respect to f0 -- the only gradient the reference lets through
+ * (utils/local_correlation.py:54-60: sampling coordinates and feature1 are used under no_grad):
+ *   grad_f0[b,c,i,j] = (sum_k grad_out[b,k,i,j] * bilinear(f1[b,c], tap k of cell (i,j))) / sqrt(C).
+ * Same arguments as the forward; grad_out (B,K,G,G) with batch stride grad_out_bs, grad_f0 (B,C,G,G) with grad_f0_bs. */
+int gfn_local_corr_bwd_f0(const float *grad_out, int64_t grad_out_bs, const float *f1, const float *f1_second, const float *flow,
+                          float *grad_f0, int64_t grad_f0_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
+                          int win_w, gfn_stream_t stream);
+
 /* F.avg_pool2d(x, 2, 2) between correlation levels (utils/local_correlation.py:71).
  * in (BC,H,W) -> out (BC,H/2,W/2). */
 int gfn_avg_pool2(const float *in, float *out, int BC, int H, int W, gfn_stream_t stream);

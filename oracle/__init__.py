@@ -94,6 +94,25 @@ def local_correlation(featuremap_size, feature0, feature1, local_radius, num_gri
     return out
 
 
+def local_correlation_grad_feature0(featuremap_size, grad_out, feature1, local_radius, num_grid, flow=None,
+                                    grid_based_correlation=False, num_level=1, variant="f64"):
+    """d(sum(grad_out * local_correlation(f0, ...))) / d f0.  The forward is linear in feature0 with a
+    per-cell, per-channel coefficient S[b,c,i,j,k] (local_correlation.py:60; nothing else gets a gradient, :54), so the
+    gradient is read off the pinned forward itself: run it with feature0 = one-hot channel c to obtain S / sqrt(C) and
+    contract with grad_out over the K taps."""
+    B, c, h, w = [int(v) for v in featuremap_size]
+    G = int(num_grid)
+    g = np.asarray(grad_out, np.float64)
+    out = np.zeros((B, c, G, G), np.float64)
+    for ch in range(c):
+        e = np.zeros((B, c, G, G), np.float32)
+        e[:, ch] = 1.0
+        s = local_correlation(featuremap_size, e, feature1, local_radius, G, flow=flow, grid_based_correlation=grid_based_correlation,
+                              num_level=num_level, variant=variant)
+        out[:, ch] = (g * s).sum(axis=1)
+    return out
+
+
 def corr_volume(feat0, feat1, variant="f32"):
     """model/network.py:415-428 -> (B,H1,W1,H0,W0)."""
     f0, f1 = _f32(feat0), _f32(feat1)

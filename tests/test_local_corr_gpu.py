@@ -170,3 +170,44 @@ def test_config3_672_shapes_vs_oracle(c, hs, G, r):
     out = run(f0, f1, flow, r, G)
     ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
     assert_close(out, ref, TOL, f"672: c{c} hs{hs} G{G} r{r}")
+
+
+# ---- N4: gradient w.r.t. feature0 ---------------------------------------------------------------------
+@pytest.mark.parametrize("B,c,h,w,G,r,num_level,grid_based", [(2, 4, 7, 9, 5, 1, 1, False), (1, 19, 12, 12, 8, 2, 1, False),
+                                                              (2, 16, 16, 16, 16, 3, 2, False), (1, 8, 10, 14, 6, 2, 1, True)])
+def test_local_correlation_backward_feature0(B, c, h, w, G, r, num_level, grid_based):
+    """The reference lets gradients reach feature0 only (local_correlation.py:54-60).  autograd through the wrapper
+    (gfn_local_corr_bwd_f0) against the oracle's gradient, which is read off the pinned forward by linearity."""
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    f0 = synth.lattice_normalish((B, c, G, G), 501)
+    f1 = synth.lattice_normalish((B, c, h, w), 502)
+    flow = (synth.lattice_uniform((B, 2, G, G), 503) * 0.9).astype(np.float32)
+    K = (2 * r + 1) ** 2 * num_level
+    g = synth.lattice_normalish((B, K, G, G), 504)
+    t0 = torch.from_numpy(f0).cuda().requires_grad_(True)
+    t1 = torch.from_numpy(f1).cuda().requires_grad_(True)
+    tf = torch.from_numpy(flow).cuda().requires_grad_(True)
+    out = local_correlation((B, c, h, w), t0, t1, r, G, flow=tf, grid_based_correlation=grid_based, num_level=num_level)
+    assert out.requires_grad
+    want_fwd = oracle.local_correlation((B, c, h, w), f0, f1, r, G, flow=flow, grid_based_correlation=grid_based, num_level=num_level)
+    assert_close(out.detach().cpu().numpy(), want_fwd, 1e-4, "forward under autograd")
+    (out * torch.from_numpy(g).cuda()).sum().backward()
+    assert t1.grad is None and tf.grad is None  # sampling runs under no_grad in the reference
+    want = oracle.local_correlation_grad_feature0((B, c, h, w), g, f1, r, G, flow=flow, grid_based_correlation=grid_based,
+                                                  num_level=num_level)
+    assert_close(t0.grad.cpu().numpy(), want, 1e-4, "grad feature0")
+
+
+def test_local_correlation_no_grad_paths_unchanged():
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B, c, h, w, G, r = 1, 16, 12, 12, 8, 2
+    t0 = torch.from_numpy(synth.lattice_normalish((B, c, G, G), 511)).cuda().requires_grad_(True)
+    t1 = torch.from_numpy(synth.lattice_normalish((B, c, h, w), 512)).cuda()
+    fl = torch.from_numpy((synth.lattice_uniform((B, 2, G, G), 513) * 0.9).astype(np.float32)).cuda()
+    with torch.no_grad():
+        a = local_correlation((B, c, h, w), t0, t1, r, G, flow=fl)
+    assert not a.requires_grad
+    b = local_correlation((B, c, h, w), t0, t1, r, G, flow=fl)
+    assert b.requires_grad and torch.equal(a, b.detach())
