@@ -211,3 +211,19 @@ def test_local_correlation_no_grad_paths_unchanged():
     assert not a.requires_grad
     b = local_correlation((B, c, h, w), t0, t1, r, G, flow=fl)
     assert b.requires_grad and torch.equal(a, b.detach())
+
+
+def test_local_correlation_fp16_features():
+    """fp16 feature storage (BASELINE config 5): inputs are widened to fp32 for the kernels, the result comes back in
+    feature0's dtype like the reference's (local_correlation.py returns feature0.dtype math under autocast)."""
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B, c, h, w, G, r = 2, 32, 28, 28, 16, 4
+    f0 = synth.lattice_normalish((B, c, G, G), 601).astype(np.float16)
+    f1 = synth.lattice_normalish((B, c, h, w), 602).astype(np.float16)
+    flow = (synth.lattice_uniform((B, 2, G, G), 603) * 0.9).astype(np.float32)
+    out = local_correlation((B, c, h, w), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G,
+                            flow=torch.from_numpy(flow).cuda())
+    assert out.dtype == torch.float16
+    want = oracle.local_correlation((B, c, h, w), f0.astype(np.float32), f1.astype(np.float32), r, G, flow=flow)
+    assert_close(out.float().cpu().numpy(), want, 2e-3, "fp16 features")  # one fp16 rounding of the result
