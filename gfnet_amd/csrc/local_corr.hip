@@ -70,8 +70,11 @@ struct LcParams {
 
 #ifdef GFN_ABLATE
 #define ABL(p, bit) (((p).dbg & (bit)) != 0)
+// phase time stamps of one workgroup (tools/ablate_local_corr.py --stamps): s_memtime at the phase boundaries
+#define STAMP(i) do { if (stamping) stamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ABL(p, bit) false
+#define STAMP(i) do { } while (0)
 #endif
 
 // f1 map of direction b.  Symmetric batches are virtual: the second half of the directions reads
@@ -329,6 +332,11 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G, H = p.H, W = p.W;
+#ifdef GFN_ABLATE
+    const bool stamping = ABL(p, 512) && blockIdx.x == 2000 && tid == 0 && !SECOND;
+    long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
     auto cell_gi = [&](int cell) { return row0 + cell / TW; };
     auto cell_gj = [&](int cell) { return col0 + cell % TW; };
     auto cell_ok = [&](int cell) { return (cell / TW < rows) & (row0 + cell / TW < G) & (col0 + cell % TW < G); };
@@ -414,7 +422,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     }
     // the zero slot (index kCapSlots) is what every out-of-image tap reads
     if (STAGED && tid < kSlotV4) s4[kCapSlots * kSlotV4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     // ---- the staging region (block-uniform) -----------------------------------------------------
     Region u;
@@ -468,6 +478,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         }
     }
 
+    STAMP(3);
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
     const float *f1b = f1_of(p, b);
@@ -479,6 +490,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         stage_rest<2>(s4, f1b, H, W, u, wave, lane, PRE);
     }
     if (STAGED) __syncthreads();
+    STAMP(4);
     for (int c0 = 0; c0 < p.C; c0 += kChunk) {
         const float *f1c = f1b + (size_t)c0 * H * W;
         const bool more = c0 + kChunk < p.C;
@@ -542,6 +554,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int t = 0; t < NP; ++t) asm volatile("" : "+v"(acc[rd][t]));  // pins the FMAs above this point
+        STAMP(5 + (c0 != 0 ? 2 : 0));
         if (STAGED && more) {
             __syncthreads();  // everyone is done reading this chunk
             if (!ABL(p, 1)) {
@@ -549,11 +562,13 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                 stage_rest<2>(s4, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, PRE);
             }
             __syncthreads();
+            STAMP(6);
         }
     }
 
     // ---- epilogue: D -> LDS, per-tap fractions, bilinear combination, coalesced stores -------
     __syncthreads();
+    STAMP(8);
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
@@ -582,6 +597,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         tab[cell * TS + a] = pix - fl;
     }
     __syncthreads();
+    STAMP(9);
     {
         // each wave combines CW cells x a strided subset of the K taps: lane -> cell (so that stores run
         // along the grid row), taps strided over the waves (and over lane halves when NC == 32)
@@ -626,6 +642,14 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         }
     }
 
+    STAMP(10);
+#ifdef GFN_ABLATE
+    if (stamping)
+        printf("stamps(cycles from entry): setup-done %lld | barrier %lld | addressing %lld | chunk0 staged %lld | D chunk0 %lld | chunk1 staged %lld | "
+               "D chunk1 %lld | barrier %lld | dbuf+table %lld | combine+stores issued %lld\n",
+               stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0],
+               stamp[7] - stamp[0], stamp[8] - stamp[0], stamp[9] - stamp[0], stamp[10] - stamp[0]);
+#endif
     // ---- flagged cells: general per-tap routine (about one cell in 10^4) ------------------------
     if (*nSlow != 0 && !ABL(p, 16)) {  // block-uniform, rare
         for (int cell = 0; cell < NC; ++cell) {
