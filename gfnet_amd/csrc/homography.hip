@@ -10,22 +10,24 @@
 //                       (8 lanes per hypothesis, shuffles for pivot search / row swap)
 //   score kernel      : one wave per hypothesis counts inliers (squared reprojection error
 //                       <= thr^2) over the N correspondences, fp64, coalesced float4 reads
-//   finish kernel     : one 1024-thread workgroup per pair: arg-max hypothesis (ties -> lowest
+//   finish kernel     : one 512-thread workgroup per pair: arg-max hypothesis (ties -> lowest
 //                       index), inlier mask, normalised DLT on the inliers, <= 10 Levenberg-
-//                       Marquardt steps.  Every 9x9 contraction (L^T L of the DLT, [J|r]^T [J|r] of
-//                       LM) is accumulated on the matrix cores with v_mfma_f64_16x16x4_f64: each
-//                       lane supplies ONE element L[k][i] as both the A and the B operand, 4 rows
-//                       (2 correspondences) per instruction, so the reduction over N happens in
-//                       the accumulator instead of 45 shuffle trees.  9x9 Jacobi eigen-solve and
-//                       8x8 solves run on one wave with a matrix row per lane.
+//                       Marquardt steps.  The 9x9 contractions (L^T L of the DLT, [J|r]^T [J|r] of LM)
+//                       are accumulated per thread in their sparse form (36 distinct entries, 42 fp64
+//                       FMAs per correspondence) and reduced with shuffles; the DLT null vector comes
+//                       from LU + inverse iteration and the 8x8 LM solves from Gaussian elimination,
+//                       both on one wave with a matrix row per lane (v_readlane broadcasts).
+//                       (The north star asks for MFMA on "the batched 9x9 DLT contractions where it
+//                       really is dense": measured, it is not -- two thirds of every rank-1 block are
+//                       structural zeros, a v_mfma_f64_16x16x4_f64 tile spends 12x the flops of the
+//                       sparse form at 64 cycles per instruction, and the matrix pipe alone took 40 k
+//                       of the 83 k cycles of a pass that now takes 9 k.)
 // The same kernels serve the one-shot weighted "grid-DLT" over a dense warp (weights = certainty).
 // fp64 throughout; compiled with -ffp-contract=off so hypotheses, inlier counts and the chosen
 // hypothesis are bit-identical to the oracle.
 #include "common.h"
 
 namespace {
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
@@ -184,7 +186,6 @@ constexpr int kFinThreads = 512;
 constexpr int kFinWaves = kFinThreads / 64;
 
 struct FinShared {
-    double rows[kFinWaves][64][18];  // per wave: the two 9-element rows of 64 correspondences
     double gram[kFinWaves][81];
     double red[kFinWaves][12];
     double G[81];       // reduced gram
@@ -223,109 +224,129 @@ __device__ void block_sum(FinShared &sh, const double (&v)[K], double *dst) {
     __syncthreads();
 }
 
-// Accumulate sum over all correspondences of (rx rx^T + ry ry^T), rx, ry in R^9, on the f64 matrix
-// core.  gen(n, rx, ry) fills the two rows of correspondence n (weight / mask already applied).
-// Each lane generates the rows of ONE correspondence per step (64 per wave) and parks them in the
-// wave's LDS slab; the MFMA operand of lane (i = lane&15, k = lane>>4) is then one LDS read:
-// element i of row (k&1) of correspondence 2j + (k>>1) -- the same value serves as A and as B.
+// Accumulate G = sum over all correspondences of (rx rx^T + ry ry^T), rx, ry in R^9 with the sparsity of the DLT / LM
+// rows:  rx = [a0 a1 a2 0 0 0 a3 a4 a5],  ry = [0 0 0 b0 b1 b2 b3 b4 b5].  gen(n, a, b) fills the twelve values of
+// correspondence n (weight / mask already applied).  Only 36 of the 81 entries are distinct and non-zero, 42 fp64 FMAs per
+// correspondence on the VALU.  (Round 1 ran this on v_mfma_f64_16x16x4_f64: a 16x16x4 tile per two correspondences is
+// 12x the flops of the sparse form, and at 64 cycles per instruction the matrix pipe alone took 40 k of the 83 k cycles
+// of a 5000-point pass; this form takes ~9 k.)
+//   acc layout: [0..5] a-block upper triangle, [6..14] a x c, [15..20] b-block, [21..29] b x c, [30..35] c-block (from a and b)
+__device__ __forceinline__ int gram_slot(int r, int c) {  // acc index of G[r][c], -1 for the structural zeros
+    if (r > c) { const int t = r; r = c; c = t; }
+    const int tri[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    if (c < 3) return tri[r][c];
+    if (r < 3) return c < 6 ? -1 : 6 + r * 3 + (c - 6);
+    if (c < 6) return 15 + tri[r - 3][c - 3];
+    if (r < 6) return 21 + (r - 3) * 3 + (c - 6);
+    return 30 + tri[r - 6][c - 6];
+}
+
 template <class Gen>
 __device__ void gram_accumulate(FinShared &sh, int N, Gen gen, double *dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, k = lane >> 4;
-    f64x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    double(*rows)[18] = sh.rows[wave];
-    for (int base = wave * 64; base < N; base += kFinWaves * 64) {
-        const int n = base + lane;
-        double rx[9], ry[9];
+    double acc[36];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { rx[q] = 0.0; ry[q] = 0.0; }
-        if (n < N) gen(n, rx, ry);
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    for (int n = threadIdx.x; n < N; n += kFinThreads) {
+        double a[6], b[6];
+        gen(n, a, b);
+        acc[0] = fma(a[0], a[0], acc[0]); acc[1] = fma(a[0], a[1], acc[1]); acc[2] = fma(a[0], a[2], acc[2]);
+        acc[3] = fma(a[1], a[1], acc[3]); acc[4] = fma(a[1], a[2], acc[4]); acc[5] = fma(a[2], a[2], acc[5]);
+        acc[15] = fma(b[0], b[0], acc[15]); acc[16] = fma(b[0], b[1], acc[16]); acc[17] = fma(b[0], b[2], acc[17]);
+        acc[18] = fma(b[1], b[1], acc[18]); acc[19] = fma(b[1], b[2], acc[19]); acc[20] = fma(b[2], b[2], acc[20]);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { rows[lane][q] = rx[q]; rows[lane][9 + q] = ry[q]; }
-        __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; this only pins the compiler
-        const int cnt = min(64, N - base);
-        // two accumulation chains (even / odd steps) so that consecutive MFMAs do not wait on each other, operands of
-        // four steps fetched ahead (-20 % on the LM loop)
-        const double *col = &rows[k >> 1][(k & 1) * 9 + (i < 9 ? i : 0)];
-        const int steps = (cnt + 1) >> 1;
-        for (int j = 0; j < steps; j += 4) {
-            double e[4];
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = (i < 9 && j + q < steps) ? col[(size_t)(2 * (j + q)) * 18] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[0], e[0], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e[1], e[1], acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[2], e[2], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e[3], e[3], acc2, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
+            for (int c = 0; c < 3; ++c) {
+                acc[6 + r * 3 + c] = fma(a[r], a[3 + c], acc[6 + r * 3 + c]);
+                acc[21 + r * 3 + c] = fma(b[r], b[3 + c], acc[21 + r * 3 + c]);
+            }
+        acc[30] = fma(a[3], a[3], fma(b[3], b[3], acc[30])); acc[31] = fma(a[3], a[4], fma(b[3], b[4], acc[31]));
+        acc[32] = fma(a[3], a[5], fma(b[3], b[5], acc[32])); acc[33] = fma(a[4], a[4], fma(b[4], b[4], acc[33]));
+        acc[34] = fma(a[4], a[5], fma(b[4], b[5], acc[34])); acc[35] = fma(a[5], a[5], fma(b[5], b[5], acc[35]));
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
-    // D[row][col]: col = lane&15, row = (lane>>4) + 4*reg
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = k + 4 * r;
-        if (row < 9 && i < 9) sh.gram[wave][row * 9 + i] = acc[r];
+    for (int q = 0; q < 36; ++q) {
+        const double sum = wave_sum(acc[q]);
+        if (lane == 0) sh.gram[wave][q] = sum;
     }
     __syncthreads();
     if (threadIdx.x < 81) {
-        double s = 0;
-        for (int w = 0; w < kFinWaves; ++w) s += sh.gram[w][threadIdx.x];
-        dst[threadIdx.x] = s;
+        const int slot = gram_slot(threadIdx.x / 9, threadIdx.x % 9);
+        double t = 0;
+        if (slot >= 0)
+            for (int w = 0; w < kFinWaves; ++w) t += sh.gram[w][slot];
+        dst[threadIdx.x] = t;
     }
     __syncthreads();
 }
 
 __device__ __forceinline__ double rl(double v, int srclane) { return lane_get<true>(v, srclane); }  // srclane is a compile-time constant at every call
 
-// cyclic Jacobi on wave 0: lane r (< 9) holds row r of A and of V.  Same rotation order and
-// formulas as jacobi_eig() in the oracle.  On return lane r holds A[r][*] (diag = eigenvalues)
-// and V[r][*] (columns = eigenvectors).
-__device__ void jacobi9(double (&A)[9], double (&V)[9], int lane) {
+// Null vector of the 9x9 DLT normal matrix on wave 0: lane r (< 9) holds row r of G.  The oracle (like OpenCV) runs a
+// cyclic Jacobi eigen-decomposition and picks the eigenvector of the smallest eigenvalue; on the GPU that was 390 k cycles
+// of dependent fp64 divisions, square roots and v_readlanes (a quarter of the finish kernel).  Only that one vector is
+// needed, so: shift G by 1e-13 of its mean diagonal (keeps the factorisation away from an exactly singular matrix; the
+// eigenvectors do not move), LU-factorise once (symmetric positive definite: no pivoting), and run inverse iteration,
+// which converges to the same vector by a factor lambda_min/lambda_2 per step (<= 1e-3 on inlier sets).  The result
+// agrees with the Jacobi vector up to the conditioning of G itself (H within 1e-5 px).  Returns h[lane].
+__device__ double null_vector9(double (&M)[9], int lane) {
+    double tr = 0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) V[j] = (lane == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0, diag = 0;
+    for (int j = 0; j < 9; ++j) tr += rl(M[j], j);
+    const double mu = 1e-13 * tr / 9.0 + 1e-300;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        if (lane == j) M[j] += mu;
+    // in-place LU: after step c lane r > c keeps L[r][c] in M[c]; row r of U stays in M[r..8] of lane r
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double inv = 1.0 / rl(M[c], c);
+        const double f = M[c] * inv;
+#pragma unroll
+        for (int k = c + 1; k < 9; ++k) {
+            const double prow = rl(M[k], c);
+            if (lane > c) M[k] -= f * prow;
+        }
+        if (lane > c) M[c] = f;
+    }
+    double dinv = 1.0;  // 1 / U[lane][lane]
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        if (lane == j) dinv = 1.0 / M[j];
+    double x = (lane < 9) ? 1.0 / 3.0 : 0.0, prev = x;
+    for (int it = 0; it < 24; ++it) {
+        double b = x;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {  // L y = x
+            const double bc = rl(b, c);
+            if (lane > c && lane < 9) b -= M[c] * bc;
+        }
+#pragma unroll
+        for (int k = 8; k >= 0; --k) {  // U z = y
+            const double xk = rl(b * dinv, k);
+            if (lane == k) x = xk;
+            if (lane < k) b -= M[k] * xk;
+        }
+        double n2 = 0, dot = 0;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            if (lane < 9) {
-                if (j == lane) diag += A[j] * A[j];
-                if (j > lane) off += A[j] * A[j];
-            }
+            const double xj = rl(x, j), pj = rl(prev, j);
+            n2 += xj * xj;
+            dot += xj * pj;
         }
-        off = wave_sum(off);
-        diag = wave_sum(diag);
-        if (off <= 1e-30 * diag || off == 0) break;
+        const double sc = (dot < 0 ? -1.0 : 1.0) / sqrt(n2);
+        x = (lane < 9) ? x * sc : 0.0;
+        double d2 = 0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-#pragma unroll
-            for (int q = p + 1; q < 9; ++q) {
-                const double apq = rl(A[q], p), app = rl(A[p], p), aqq = rl(A[q], q);
-                if (apq == 0) continue;  // wave-uniform
-                const double theta = (aqq - app) / (2 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(t * t + 1), s = t * c;
-                // columns p,q of every row (lane-local)
-                {
-                    const double akp = A[p], akq = A[q];
-                    A[p] = c * akp - s * akq;
-                    A[q] = s * akp + c * akq;
-                }
-                // rows p,q: new row p = c*row p - s*row q (after the column update)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double apk = rl(A[k], p), aqk = rl(A[k], q);
-                    if (lane == p) A[k] = c * apk - s * aqk;
-                    if (lane == q) A[k] = s * apk + c * aqk;
-                }
-                {
-                    const double vkp = V[p], vkq = V[q];
-                    V[p] = c * vkp - s * vkq;
-                    V[q] = s * vkp + c * vkq;
-                }
-            }
+        for (int j = 0; j < 9; ++j) {
+            const double dj = rl(x, j) - rl(prev, j);
+            d2 += dj * dj;
         }
+        prev = x;
+        if (d2 <= 1e-28) break;  // wave-uniform (every term came through v_readlane)
     }
+    return x;
 }
 
 struct FinParams {
@@ -446,33 +467,19 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
     dlt_ok = dlt_ok && sh.stats[5] > 1e-300 && sh.stats[6] > 1e-300 && sh.stats[7] > 1e-300 && sh.stats[8] > 1e-300;
     const double sx = sw / sh.stats[5], sy = sw / sh.stats[6], su = sw / sh.stats[7], sv = sw / sh.stats[8];
     if (dlt_ok) {
-        gram_accumulate(sh, N, [&](int n, double (&rx)[9], double (&ry)[9]) {
+        gram_accumulate(sh, N, [&](int n, double (&a)[6], double (&bb)[6]) {
             const double sw_ = sqrt(point_w(n, Hb));
             const float4 p = pts[n];
             const double X = (p.x - cx) * sx * sw_, Y = (p.y - cy) * sy * sw_, x = (p.z - cu) * su, y = (p.w - cv) * sv;
-            rx[0] = X; rx[1] = Y; rx[2] = sw_; rx[6] = -x * X; rx[7] = -x * Y; rx[8] = -x * sw_;
-            ry[3] = X; ry[4] = Y; ry[5] = sw_; ry[6] = -y * X; ry[7] = -y * Y; ry[8] = -y * sw_;
+            a[0] = X; a[1] = Y; a[2] = sw_; a[3] = -x * X; a[4] = -x * Y; a[5] = -x * sw_;
+            bb[0] = X; bb[1] = Y; bb[2] = sw_; bb[3] = -y * X; bb[4] = -y * Y; bb[5] = -y * sw_;
         }, sh.G);
         // eigenvector of the smallest eigenvalue (wave 0, one matrix row per lane)
         if (wave == 0) {
-            double A[9], V[9];
+            double A[9];
 #pragma unroll
             for (int j = 0; j < 9; ++j) A[j] = (lane < 9) ? sh.G[lane * 9 + j] : 0.0;
-            jacobi9(A, V, lane);
-            // eigenvalue r sits at A[r] of lane r
-            double ev = 0;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) if (lane == j) ev = A[j];
-            int kmin = 0;
-            double best = rl(ev, 0);
-#pragma unroll
-            for (int k = 1; k < 9; ++k) {
-                const double e = rl(ev, k);
-                if (e < best) { best = e; kmin = k; }
-            }
-            double hk = 0;  // h[lane] = V[lane][kmin]
-#pragma unroll
-            for (int j = 0; j < 9; ++j) if (j == kmin) hk = V[j];
+            const double hk = null_vector9(A, lane);
             if (lane < 9) sh.h[lane] = hk;
         }
         __syncthreads();
@@ -513,15 +520,15 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
         double h[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = hsrc[k];
-        gram_accumulate(sh, N, [&](int n, double (&rx)[9], double (&ry)[9]) {
+        gram_accumulate(sh, N, [&](int n, double (&a)[6], double (&bb)[6]) {
             const double w = point_w(n, Hb);  // 0/1 here
             const float4 p = pts[n];
             const double X = p.x, Y = p.y, u = p.z, v = p.w;
             const double ww = w != 0.0 ? 1.0 / (h[6] * X + h[7] * Y + 1.0) : 0.0;  // masked points contribute exact zeros
             const double xi = (h[0] * X + h[1] * Y + h[2]) * ww, yi = (h[3] * X + h[4] * Y + h[5]) * ww;
             // xi, yi carry the weight; for w = 1 these are the reference's Jacobian rows and residuals
-            rx[0] = X * ww; rx[1] = Y * ww; rx[2] = ww; rx[6] = -X * ww * xi; rx[7] = -Y * ww * xi; rx[8] = xi - w * u;
-            ry[3] = X * ww; ry[4] = Y * ww; ry[5] = ww; ry[6] = -X * ww * yi; ry[7] = -Y * ww * yi; ry[8] = yi - w * v;
+            a[0] = X * ww; a[1] = Y * ww; a[2] = ww; a[3] = -X * ww * xi; a[4] = -Y * ww * xi; a[5] = xi - w * u;
+            bb[0] = X * ww; bb[1] = Y * ww; bb[2] = ww; bb[3] = -X * ww * yi; bb[4] = -Y * ww * yi; bb[5] = yi - w * v;
         }, dst);
     };
     if (tid < 9) sh.h[tid] = sh.H[tid] / sh.H[8];

@@ -210,6 +210,9 @@ def test_ransac_matches_oracle_hypothesis_for_hypothesis(stage):
     Hg = host(H)
     for b in range(4):
         assert _ace(Ho[b], Hg[b]) < 1e-3, (stage, b, _ace(Ho[b], Hg[b]))  # north_star: within 1e-3 px of the reference path
+        if stage == 2:  # DLT null vector: LU + inverse iteration on the GPU, Jacobi in the oracle -- same vector up to the
+            # conditioning of the normal matrix (its 1e-16 summation-order differences over an eigen-gap of ~1e-8)
+            assert _ace(Ho[b], Hg[b]) < 1e-4, (b, _ace(Ho[b], Hg[b]))
         if stage == 0:
             assert _ace(Hs[b], Hg[b]) < 0.3
 
@@ -233,13 +236,13 @@ def test_ransac_noise_free_and_failure_convention():
 def test_weighted_grid_dlt_matches_oracle():
     from gfnet_amd import ops
 
-    Hs, pts = _points(23, 3, 4001, noise=0.4, outliers=0.0)  # odd count: exercises the MFMA tail
+    Hs, pts = _points(23, 3, 4001, noise=0.4, outliers=0.0)  # odd count: a ragged last round of the per-thread accumulation
     w = np.random.default_rng(3).uniform(0.05, 1.0, size=(3, 4001)).astype(np.float32)
     H, ok = ops.homography_dlt(dev(pts), dev(w))
     Ho, oko = oracle.homography_dlt(pts, w.astype(np.float64))
     assert host(ok).all() and oko.all()
     for b in range(3):
-        assert _ace(Ho[b], host(H)[b]) < 1e-3
+        assert _ace(Ho[b], host(H)[b]) < 1e-4, _ace(Ho[b], host(H)[b])
         assert _ace(Hs[b], host(H)[b]) < 0.2
     H1, _ = ops.homography_dlt(dev(pts), None)
     Ho1, _ = oracle.homography_dlt(pts)
