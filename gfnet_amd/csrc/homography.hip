@@ -114,12 +114,17 @@ __device__ double ge_solve8(double (&M)[9], int row, int base, bool &ok) {
     return x;
 }
 
-__device__ __forceinline__ double reproj_err2(const double (&H)[9], const float4 p) {
-    const double x = p.x, y = p.y, u = p.z, v = p.w;
-    const double rw = 1.0 / (H[6] * x + H[7] * y + H[8]);  // one division; same sequence as the oracle
-    const double dx = (H[0] * x + H[1] * y + H[2]) * rw - u;
-    const double dy = (H[3] * x + H[4] * y + H[5]) * rw - v;
-    return dx * dx + dy * dy;
+// Inlier test: squared reprojection error <= thr2, multiplied through by w^2 so that no division is needed -- the same
+// operation sequence as is_inlier() in the oracle (bit-identical decisions).
+__device__ __forceinline__ bool is_inlier(const double (&H)[9], double x, double y, double u, double v, double thr2) {
+    const double w = H[6] * x + H[7] * y + H[8];
+    const double dx = (H[0] * x + H[1] * y + H[2]) - u * w;
+    const double dy = (H[3] * x + H[4] * y + H[5]) - v * w;
+    const double w2 = w * w;
+    return (dx * dx + dy * dy <= thr2 * w2) & (w2 > 0);
+}
+__device__ __forceinline__ bool is_inlier(const double (&H)[9], const float4 p, double thr2) {
+    return is_inlier(H, (double)p.x, (double)p.y, (double)p.z, (double)p.w, thr2);
 }
 
 // ---- kernel 1: hypotheses ---------------------------------------------------------------------
@@ -162,23 +167,43 @@ __global__ __launch_bounds__(256) void hyp_kernel(const float *__restrict__ pts,
 }
 
 // ---- kernel 2: inlier counts --------------------------------------------------------------------
+// One wave scores kHypPerWave hypotheses of one pair: every correspondence is loaded and widened to fp64 once per group
+// (the 2000 hypotheses of a pair re-read the same 80 KB of points; at one hypothesis per wave that was 5 GB of L2 -> L1
+// traffic per 32-pair batch and four conversions per test).
+constexpr int kHypPerWave = 4;  // 8 measured slower (register pressure / fewer waves)
 __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ pts, const double *__restrict__ hyp,
                                                     int *__restrict__ counts, int Bt, int N, int T, double thr2) {
     const int lane = threadIdx.x & 63;
+    const int groups = (T + kHypPerWave - 1) / kHypPerWave;
     const long gid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gid >= (long)Bt * T) return;
-    const int b = (int)(gid / T);
-    double H[9];
+    if (gid >= (long)Bt * groups) return;
+    const int b = (int)(gid / groups), t0 = (int)(gid - (long)b * groups) * kHypPerWave;
+    double H[kHypPerWave][9];
+    bool valid[kHypPerWave];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) H[k] = hyp[(size_t)gid * 9 + k];
-    int c = 0;
-    if (H[8] == 1.0) {  // NaN marks an invalid hypothesis
-        const float4 *p = reinterpret_cast<const float4 *>(pts) + (size_t)b * N;
-        for (int n = lane; n < N; n += 64) c += (reproj_err2(H, p[n]) <= thr2) ? 1 : 0;
+    for (int h = 0; h < kHypPerWave; ++h) {
+        const int t = min(t0 + h, T - 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[h][k] = hyp[((size_t)b * T + t) * 9 + k];
+        valid[h] = H[h][8] == 1.0;  // NaN marks an invalid hypothesis
+    }
+    int c[kHypPerWave];
+#pragma unroll
+    for (int h = 0; h < kHypPerWave; ++h) c[h] = 0;
+    const float4 *p = reinterpret_cast<const float4 *>(pts) + (size_t)b * N;
+    for (int n = lane; n < N; n += 64) {
+        const float4 q = p[n];
+        const double x = q.x, y = q.y, u = q.z, v = q.w;
+#pragma unroll
+        for (int h = 0; h < kHypPerWave; ++h) c[h] += is_inlier(H[h], x, y, u, v, thr2) ? 1 : 0;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) counts[gid] = c;
+    for (int h = 0; h < kHypPerWave; ++h) {
+        int s = valid[h] ? c[h] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && t0 + h < T) counts[(size_t)b * T + t0 + h] = s;
+    }
 }
 
 // ---- kernel 3: per-pair finish ------------------------------------------------------------------
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
         for (int k = 0; k < 9; ++k) Hb[k] = sh.H[k];
         int c = 0;
         for (int n = tid; n < N; n += kFinThreads) {
-            const bool in = best >= 0 && reproj_err2(Hb, pts[n]) <= P.thr2;
+            const bool in = best >= 0 && is_inlier(Hb, pts[n], P.thr2);
             if (mask) mask[n] = in ? 1 : 0;
             c += in ? 1 : 0;
         }
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
 
     // per-point weight (mask in ransac mode, certainty in dlt mode)
     auto point_w = [&](int n, const double (&Hb)[9]) -> double {
-        if (P.mode == 0) return reproj_err2(Hb, pts[n]) <= P.thr2 ? 1.0 : 0.0;
+        if (P.mode == 0) return is_inlier(Hb, pts[n], P.thr2) ? 1.0 : 0.0;
         return wgt ? (double)wgt[n] : 1.0;
     };
     double Hb[9];
@@ -621,7 +646,8 @@ GFN_EXPORT int gfn_homography_ransac(const float *pts, int Bt, int N, double thr
     const long nh = (long)Bt * iters;
     hipLaunchKernelGGL(hyp_kernel, dim3((unsigned)((nh * 8 + 255) / 256)), dim3(256), 0, s, pts, hyp, Bt, N, iters, seed);
     if (int e = gfn::check_launch("hyp_kernel")) return e;
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, pts, hyp, counts, Bt, N, iters,
+    const long ngroups = (long)Bt * ((iters + kHypPerWave - 1) / kHypPerWave);
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pts, hyp, counts, Bt, N, iters,
                        thresh * thresh);
     if (int e = gfn::check_launch("score_kernel")) return e;
     FinParams P;

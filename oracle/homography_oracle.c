@@ -100,13 +100,18 @@ static int solve4(const float *pts, const uint32_t idx[4], double H[9]) {
     return 1;
 }
 
-/* squared reprojection error of one correspondence (OpenCV HomographyEstimatorCallback::computeError) */
-static inline double reproj_err2(const double H[9], const float *p) {
+/* Inlier test of one correspondence: squared reprojection error <= thr2 (OpenCV HomographyEstimatorCallback::
+ * computeError followed by the threshold test of RANSAC).  With (X, Y, w) = H (x, y, 1)^T the error is
+ * (X/w - u)^2 + (Y/w - v)^2; multiplied through by w^2 the test reads (X - u w)^2 + (Y - v w)^2 <= thr2 w^2 -- no
+ * division (w = 0 never passes).  The GPU kernels evaluate exactly this sequence of operations (fp64, no contraction),
+ * so inlier counts and masks are bit-identical. */
+static inline int is_inlier(const double H[9], const float *p, double thr2) {
     const double x = p[0], y = p[1], u = p[2], v = p[3];
-    const double rw = 1.0 / (H[6] * x + H[7] * y + H[8]); /* one division, like the GPU kernel (bit-identical inlier tests) */
-    const double dx = (H[0] * x + H[1] * y + H[2]) * rw - u;
-    const double dy = (H[3] * x + H[4] * y + H[5]) * rw - v;
-    return dx * dx + dy * dy;
+    const double w = H[6] * x + H[7] * y + H[8];
+    const double dx = (H[0] * x + H[1] * y + H[2]) - u * w;
+    const double dy = (H[3] * x + H[4] * y + H[5]) - v * w;
+    const double w2 = w * w;
+    return dx * dx + dy * dy <= thr2 * w2 && w2 > 0;
 }
 
 /* cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9): A -> diag, V columns = eigenvectors */
@@ -295,12 +300,12 @@ EXPORT void oracle_homography_ransac(const float *pts, int Bt, int N, double thr
             if (!draw_sample(seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx)) continue;
             if (!solve4(p, idx, Ht)) continue;
             int c = 0;
-            for (int n = 0; n < N; ++n) c += (reproj_err2(Ht, p + 4 * n) <= thr2);
+            for (int n = 0; n < N; ++n) c += is_inlier(Ht, p + 4 * n, thr2);
             if (c > bestc) { bestc = c; best = t; memcpy(Hb, Ht, sizeof(Hb)); }
         }
         unsigned char *mk = (unsigned char *)malloc(N > 0 ? N : 1);
         int cnt = 0;
-        for (int n = 0; n < N; ++n) { mk[n] = best >= 0 && reproj_err2(Hb, p + 4 * n) <= thr2; cnt += mk[n]; }
+        for (int n = 0; n < N; ++n) { mk[n] = best >= 0 && is_inlier(Hb, p + 4 * n, thr2); cnt += mk[n]; }
         if (best < 0 || cnt < 4) {
             memset(Hb, 0, sizeof(Hb));
             Hb[8] = 1.0; /* estimation.py:74-76: failure -> diag(0,0,1) */
