@@ -31,6 +31,7 @@ _SIGNATURES = {
     "gfn_kde_msplit": [c_int, c_int, c_int],
     "gfn_kde_density": [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64, c_i64, c_double, c_vp, c_i64, c_vp],
     "gfn_kde_morton_keys": [c_vp, c_vp, c_i64, c_vp],
+    "gfn_kde_morton_sort": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp],
     "gfn_kde_density_sorted": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_double, c_vp, c_i64, c_vp],
     "gfn_threshold_certainty": [c_vp, c_vp, c_i64, c_float, c_vp],
     "gfn_balance_weights": [c_vp, c_vp, c_i64, c_float, c_float, c_vp],

@@ -97,6 +97,99 @@ __global__ __launch_bounds__(256) void kde4_morton_kernel(const float *__restric
     keys[i] = (int)key;
 }
 
+// Stable sort of one row of points by its 16-bit Morton key, one 1024-thread workgroup per row: two least-significant-
+// digit passes of 8 bits.  Per pass: digit histogram (LDS atomics), exclusive scan, then the row is walked in chunks of
+// 1024 elements IN ORDER; inside a chunk an element's rank among equal digits is (equal digits in earlier waves, from a
+// [wave][digit] table) + (equal digits in lower lanes of its own wave, from eight ballots), which keeps the sort stable and
+// the result independent of scheduling -- the same permutation a stable library sort gives.  (torch.sort of the 32 x 20000
+// keys took 0.53 ms in 76 merge-sort launches; this takes one launch.)
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / 64;
+
+__device__ __forceinline__ unsigned morton16(float4 v) {
+    const unsigned qx = (unsigned)fminf(fmaxf((v.x + 1.f) * 128.f, 0.f), 255.f);
+    const unsigned qy = (unsigned)fminf(fmaxf((v.y + 1.f) * 128.f, 0.f), 255.f);
+    unsigned key = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) key |= (((qx >> b) & 1u) << (2 * b)) | (((qy >> b) & 1u) << (2 * b + 1));
+    return key;
+}
+
+__global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const float *__restrict__ x, float *__restrict__ xsorted,
+                                                                        int *__restrict__ perm, unsigned *__restrict__ tmp, int N) {
+    __shared__ unsigned base[256];                 // next output position of every digit
+    __shared__ unsigned short tab[kSortWaves][256];  // elements of (wave, digit) in the current chunk
+    __shared__ unsigned scan[256];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 *xr = reinterpret_cast<const float4 *>(x) + (size_t)row * N;
+    unsigned *t0 = tmp + (size_t)row * N;  // pass-0 output: (key << 16 | ... ) cannot hold the index; keep index, recompute key
+    for (int pass = 0; pass < 2; ++pass) {
+        // ---- histogram of this pass's digit
+        if (tid < 256) base[tid] = 0;
+        __syncthreads();
+        for (int n = tid; n < N; n += kSortThreads) {
+            const int src = pass == 0 ? n : (int)t0[n];
+            atomicAdd(&base[(morton16(xr[src]) >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        // ---- exclusive scan of 256 counters (one wave, four per lane)
+        if (wave == 0) {
+            unsigned c[4], s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = base[lane * 4 + q]; s += c[q]; }
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            unsigned run = incl - s;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { scan[lane * 4 + q] = run; run += c[q]; }
+        }
+        __syncthreads();
+        if (tid < 256) base[tid] = scan[tid];
+        // ---- ordered scatter
+        for (int n0 = 0; n0 < N; n0 += kSortThreads) {
+            for (int e = tid; e < kSortWaves * 256; e += kSortThreads) (&tab[0][0])[e] = 0;
+            __syncthreads();
+            const int n = n0 + tid;
+            const bool live = n < N;
+            const int src = live ? (pass == 0 ? n : (int)t0[n]) : 0;
+            const unsigned digit = live ? (morton16(xr[src]) >> (8 * pass)) & 255u : 0u;
+            // lanes of this wave with the same digit
+            unsigned long long peers = __ballot(live);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((digit >> bit) & 1u);
+                peers &= ((digit >> bit) & 1u) ? m : ~m;
+            }
+            const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+            if (live && below == 0) tab[wave][digit] = (unsigned short)__popcll(peers);
+            __syncthreads();
+            if (live) {
+                unsigned before = 0;
+                for (int w = 0; w < wave; ++w) before += tab[w][digit];
+                const unsigned pos = base[digit] + before + below;
+                if (pass == 0) {
+                    t0[pos] = (unsigned)src;
+                } else {
+                    perm[(size_t)row * N + pos] = src;
+                    reinterpret_cast<float4 *>(xsorted)[(size_t)row * N + pos] = xr[src];
+                }
+            }
+            __syncthreads();
+            if (tid < 256) {
+                unsigned tot = 0;
+#pragma unroll
+                for (int w = 0; w < kSortWaves; ++w) tot += tab[w][tid];
+                base[tid] += tot;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ys: pre-scaled point pairs (Bt, Mp/2, 4, 2) as written by kde4_prescale_kernel; box: (Bt, nblk, 8) =
 // min[4], max[4] of each block of 64 reference points (32 pairs).  One wave per block.
 __global__ __launch_bounds__(256) void kde4_bbox_kernel(const float *__restrict__ ys, float *__restrict__ box, int M, int Mp,
@@ -400,6 +493,16 @@ GFN_EXPORT int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_str
     if (n == 0) return GFN_OK;
     hipLaunchKernelGGL(kde4_morton_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, keys, (long)n);
     return gfn::check_launch("kde4_morton_kernel");
+}
+
+GFN_EXPORT int gfn_kde_morton_sort(const float *x, float *x_sorted, int *perm, int *scratch, int Bt, int N, gfn_stream_t stream) {
+    if (!x || !x_sorted || !perm || !scratch || Bt < 0 || N < 0 || (((uintptr_t)x | (uintptr_t)x_sorted) & 15))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "kde_morton_sort: bad argument");
+    if (N > 65535 * 16) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_morton_sort: row too long");
+    if (Bt == 0 || N == 0) return GFN_OK;
+    hipLaunchKernelGGL(kde4_morton_sort_kernel, dim3(Bt), dim3(kSortThreads), 0, (hipStream_t)stream, x, x_sorted, perm,
+                       reinterpret_cast<unsigned *>(scratch), N);
+    return gfn::check_launch("kde4_morton_sort_kernel");
 }
 
 // Scratch floats for gfn_kde_density_sorted: pre-scaled copies, block boxes, split-M partials.

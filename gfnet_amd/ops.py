@@ -203,17 +203,15 @@ def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None):
 
 
 def _morton_sorted(pts, dev):
-    """(sorted points, permutation): rows ordered by the Morton key of their A-image position."""
+    """(sorted points, permutation): rows stably ordered by the Morton key of their A-image position (one HIP launch:
+    in-LDS two-pass radix sort per row, the same permutation as torch.sort(keys, stable=True))."""
     Bt, N, _ = pts.shape
-    keys = torch.empty((Bt, N), device=dev, dtype=torch.int32)
-    check(_L().gfn_kde_morton_keys(ptr(pts), ptr(keys), Bt * N, stream_ptr(dev)), "gfn_kde_morton_keys")
-    # one flat radix sort of (row << 16 | 16-bit key) instead of a segmented sort per row (80 merge launches, 0.7 ms at 32 x 20000)
-    if Bt < (1 << 15):
-        keys += torch.arange(Bt, device=dev, dtype=torch.int32)[:, None] << 16
-        perm = torch.sort(keys.reshape(-1), stable=True)[1].reshape(Bt, N) - (torch.arange(Bt, device=dev) * N)[:, None]
-    else:
-        perm = torch.argsort(keys, dim=1, stable=True)
-    return torch.gather(pts, 1, perm[..., None].expand(Bt, N, 4)).contiguous(), perm
+    pts = f32c(pts)
+    out = torch.empty_like(pts)
+    perm = torch.empty((Bt, N), device=dev, dtype=torch.int32)
+    tmp = torch.empty((Bt, N), device=dev, dtype=torch.int32)
+    check(_L().gfn_kde_morton_sort(ptr(pts), ptr(out), ptr(perm), ptr(tmp), Bt, N, stream_ptr(dev)), "gfn_kde_morton_sort")
+    return out, perm.long()
 
 
 def _kde_culled(xs, ys, std, same, dev):

@@ -167,6 +167,9 @@ int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, i
  * sorted arrays; out is in the order of the sorted x.  scratch: gfn_kde_sorted_scratch_floats().
  * Blocks of 64 reference points farther than 6.7 std from a wave's 64 queries are skipped. */
 int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_stream_t stream);
+/* The order itself: rows of x (Bt,N,4) stably sorted by their Morton key, one launch.  x_sorted (Bt,N,4),
+ * perm (Bt,N): x_sorted[b][i] = x[b][perm[b][i]]; scratch: Bt*N ints. */
+int gfn_kde_morton_sort(const float *x, float *x_sorted, int *perm, int *scratch, int Bt, int N, gfn_stream_t stream);
 int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M);
 int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, int N, int M, double std, float *scratch,
                            int64_t scratch_floats, gfn_stream_t stream);

@@ -270,6 +270,22 @@ def test_symmetric_virtual_batch_equals_concatenated_batch():
     np.testing.assert_array_equal(host(f_sym), host(f_cat))
 
 
+@pytest.mark.parametrize("Bt,N", [(3, 20000), (2, 1000), (1, 1), (2, 1025)])
+def test_morton_sort_is_the_stable_sort_of_the_keys(Bt, N):
+    from gfnet_amd import ops
+    from gfnet_amd import _lib
+
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1.1, 1.1, size=(Bt, N, 4)).astype(np.float32)
+    x[:, : N // 3, :2] = np.round(x[:, : N // 3, :2] * 4) / 4        # many equal keys: stability matters
+    xs, perm = ops._morton_sorted(dev(x), torch.device("cuda"))
+    keys = torch.empty((Bt, N), device="cuda", dtype=torch.int32)
+    _lib.check(_lib.lib().gfn_kde_morton_keys(_lib.ptr(dev(x)), _lib.ptr(keys), Bt * N, _lib.stream_ptr(torch.device("cuda"))), "keys")
+    want = torch.sort(keys, dim=1, stable=True)[1]
+    assert torch.equal(perm, want)
+    np.testing.assert_array_equal(host(xs), np.take_along_axis(x, host(want)[..., None], axis=1))
+
+
 def test_kde_culled_equals_dense_and_oracle_on_match_like_points():
     """Spatially culled KDE (Morton-sorted blocks, 6.7-std cut-off) vs the dense kernel and the oracle on
     points shaped like sampled warp rows: A positions over the image, B = homography(A) + noise, some outliers."""
