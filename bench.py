@@ -285,7 +285,7 @@ def main():
         "config": {"workload": "448x448 batch=32 synthetic pairs per GPU, local_correlation radius 7/6/4/2 (BASELINE configs[1])",
                    "pairs_per_gpu": B, "symmetric": True, "upsample_pass_560": upsample, "attenuate_cert": True,
                    "stages": "corr_softargmax, refiner_input+local_corr x(4+3 scales), flow_update, resize, match_post, "
-                             "sample(multinomial+KDE 20000^2), RANSAC(2000)+DLT+LM, H all-gather",
+                             "sample(2 draws without replacement + KDE 20000^2), RANSAC(2000)+DLT+LM, H all-gather",
                    "excluded": ("DINOv2/FPN backbone and refiner conv stacks (PyTorch-ROCm host code); stand-in increment = "
                                 "exact residual to the true warp (2 torch elementwise ops per refiner call)") if args.conv_stack == "off"
                    else "DINOv2/FPN backbone (PyTorch-ROCm host code)",

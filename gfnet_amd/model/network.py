@@ -338,11 +338,12 @@ class GFNet(nn.Module):
         return good_matches[balanced], good_certainty[balanced]
 
 
-def sample_batched(model, warp, certainty, num=5_000):
+def sample_batched(model, warp, certainty, num=5_000, sampler="hip"):
     """GFNet.sample for a batch of pairs in one go: warp (B,G,Gw,4), certainty (B,G,Gw) ->
     matches (B,num,4), certainty (B,num).  Same steps as model/network.py:385-414 per pair (the
-    reference evaluates pairs one at a time); the draws use torch.multinomial row-wise and the
-    densities come from one batched KDE launch."""
+    reference evaluates pairs one at a time); the densities come from one batched KDE launch and the two draws without
+    replacement from ops.sample_without_replacement (sampler="hip": the exponential race torch.multinomial runs, seeded
+    from torch's CPU generator) or from torch.multinomial itself (sampler="torch")."""
     B = warp.shape[0]
     m = warp.reshape(B, -1, 4)
     c = certainty.reshape(B, -1)
@@ -350,7 +351,9 @@ def sample_batched(model, warp, certainty, num=5_000):
         c = ops.threshold_certainty(c, model.sample_thresh)
     expansion = 4 if "balanced" in model.sample_mode else 1
     n1 = min(expansion * num, c.shape[1])
-    good = torch.multinomial(c, num_samples=n1, replacement=False)                  # (B,n1)
+    draw = ops.sample_without_replacement if sampler == "hip" else \
+        (lambda w, k: torch.multinomial(w, num_samples=k, replacement=False))
+    good = draw(c, n1)                                                               # (B,n1)
     gm = torch.gather(m, 1, good[..., None].expand(B, n1, 4)).contiguous()
     gc = torch.gather(c, 1, good)
     if "balanced" not in model.sample_mode:
@@ -358,7 +361,7 @@ def sample_batched(model, warp, certainty, num=5_000):
     density = ops.kde_density(gm.half().float(), std=0.1)                            # half inputs, fp32 sums
     p = ops.balance_weights(density.half().float())
     n2 = min(num, n1)
-    bal = torch.multinomial(p, num_samples=n2, replacement=False)
+    bal = draw(p, n2)
     return torch.gather(gm, 1, bal[..., None].expand(B, n2, 4)).contiguous(), torch.gather(gc, 1, bal)
 
 

@@ -248,6 +248,25 @@ def balance_weights(density, min_density=10.0, floor_p=1e-7):
     return p
 
 
+def sample_without_replacement(weights, num_samples, seed=None):
+    """torch.multinomial(weights, num_samples, replacement=False) for a (Bt,N) batch (model/network.py:400-402, 411-413):
+    exponential race, one HIP launch pair; indices come back in increasing order.  seed=None draws one from torch's
+    default CPU generator, so torch.manual_seed() makes runs repeatable."""
+    dev = require_gpu(weights)
+    w = f32c(weights)
+    if w.dim() != 2:
+        raise ValueError("sample_without_replacement: weights must be (Bt, N)")
+    Bt, N = w.shape
+    K = int(num_samples)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    out = torch.empty((Bt, K), device=dev, dtype=torch.int64)
+    scratch = torch.empty((Bt, N), device=dev, dtype=torch.int32)
+    check(_L().gfn_sample_without_replacement(ptr(w), N, ptr(out), ptr(scratch), Bt, N, K, int(seed) & (2 ** 64 - 1), stream_ptr(dev)),
+          "gfn_sample_without_replacement")
+    return out
+
+
 def convert_matches(matches, wA, hA, wB, hB):
     """estimation.py:26-45 on the device: (...,4) normalised warp rows -> pixel (x,y,u,v), float32."""
     dev = require_gpu(matches)

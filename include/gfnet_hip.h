@@ -181,6 +181,14 @@ int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, i
 int gfn_threshold_certainty(const float *certainty, float *out, int64_t n, float thresh, gfn_stream_t stream);
 int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p, gfn_stream_t stream);
 
+/* Weighted sampling without replacement -- the two torch.multinomial(p, num_samples, replacement=False) draws of
+ * GFNet.sample (model/network.py:400-402, 411-413).  Exponential race like torch's implementation (key = w / Exp(1),
+ * the num_samples largest keys win) with a counter-based generator: same distribution, its own random stream, the same
+ * result for the same seed.  weights (Bt,N) with row stride row_stride (non-negative; zero-weight entries are drawn only
+ * when fewer than K positive ones exist), out (Bt,K) int64 indices in increasing order, scratch: Bt*N ints. */
+int gfn_sample_without_replacement(const float *weights, int64_t row_stride, int64_t *out, int *scratch, int Bt, int N, int K,
+                                   uint64_t seed, gfn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Homography solve -- estimation.py:60-77 (cv2.findHomography(..., cv2.RANSAC, confidence=0.99999,
  * ransacReprojThreshold=3) in the reference; OpenCV's published pipeline restated, see

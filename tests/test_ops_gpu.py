@@ -345,3 +345,50 @@ def test_resize_normalise_image_sizes_and_extra_channel():
         ops.resize_normalise(dev(x), (8, 8), "nearest")
     with pytest.raises(ValueError):
         ops.resize_normalise(dev(x[:, :2]), (8, 8))
+
+
+# ---- A7: weighted sampling without replacement ------------------------------------------------------------
+def test_sample_without_replacement_is_a_valid_draw():
+    from gfnet_amd import ops
+
+    rng = np.random.default_rng(4)
+    Bt, N, K = 3, 50000, 7000
+    w = rng.uniform(0.0, 1.0, size=(Bt, N)).astype(np.float32)
+    w[:, ::7] = 0.0                                   # zero-weight entries must never be drawn while positives remain
+    w[0, :100] = 1e6                                  # overwhelming weights are (almost surely) all drawn
+    idx = host(ops.sample_without_replacement(dev(w), K, seed=123))
+    assert idx.shape == (Bt, K) and idx.dtype == np.int64
+    for b in range(Bt):
+        assert np.all(np.diff(idx[b]) > 0)            # increasing => unique
+        assert idx[b].min() >= 0 and idx[b].max() < N
+        assert np.all(w[b, idx[b]] > 0)
+    assert np.isin(np.arange(100)[np.arange(100) % 7 != 0], idx[0]).all()
+    again = host(ops.sample_without_replacement(dev(w), K, seed=123))
+    np.testing.assert_array_equal(idx, again)         # same seed, same draw
+    other = host(ops.sample_without_replacement(dev(w), K, seed=124))
+    assert (other != idx).any()
+    # fewer positive entries than requested: the zeros fill up, in index order, every positive one is in
+    w2 = np.zeros((1, 1000), np.float32)
+    w2[0, 10:20] = 1.0
+    got = host(ops.sample_without_replacement(dev(w2), 15, seed=1))[0]
+    assert set(range(10, 20)) <= set(got.tolist()) and len(set(got.tolist())) == 15
+    # K == N: everything
+    np.testing.assert_array_equal(host(ops.sample_without_replacement(dev(w2), 1000, seed=1))[0], np.arange(1000))
+
+
+def test_sample_without_replacement_follows_the_weights():
+    """First-draw law: with K = 1 the index is drawn with probability w_i / sum(w); inclusion frequencies of a K-subset
+    must match torch.multinomial's (same exponential-race law) within sampling noise."""
+    from gfnet_amd import ops
+
+    w = np.array([0.5, 1.0, 2.0, 4.0, 0.0, 8.0, 0.25, 0.25], np.float32)
+    rows = 40000
+    W = np.tile(w, (rows, 1))
+    one = host(ops.sample_without_replacement(dev(W), 1, seed=7))[:, 0]
+    freq = np.bincount(one, minlength=8) / rows
+    np.testing.assert_allclose(freq, w / w.sum(), atol=0.01)
+    k3 = host(ops.sample_without_replacement(dev(W), 3, seed=8))
+    incl = np.bincount(k3.ravel(), minlength=8) / rows
+    ref = torch.multinomial(dev(W), 3, replacement=False)
+    incl_ref = np.bincount(host(ref).ravel(), minlength=8) / rows
+    np.testing.assert_allclose(incl, incl_ref, atol=0.015)
