@@ -23,19 +23,30 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(256) void race_keys_kernel(const float *__restrict__ w, long w_rs, unsigned *__restrict__ keys, int Bt, int N,
-                                                        uint64_t seed) {
-    const long total = (long)Bt * N;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(idx / N), i = (int)(idx - (long)row * N);
+// One workgroup = kKeysPerBlock consecutive elements of one row; besides the keys it accumulates the row's histogram of
+// the top 11 key bits (the first radix-select pass) -- in LDS, flushed with one global atomic per occupied bin.
+constexpr int kKeysPerBlock = 8192;
+__global__ __launch_bounds__(256) void race_keys_kernel(const float *__restrict__ w, long w_rs, unsigned *__restrict__ keys,
+                                                        unsigned *__restrict__ hist1, int N, int blocks_per_row, uint64_t seed) {
+    __shared__ unsigned hist[2048];
+    const int row = blockIdx.x / blocks_per_row, chunk = blockIdx.x - row * blocks_per_row;
+    for (int e = threadIdx.x; e < 2048; e += 256) hist[e] = 0;
+    __syncthreads();
+    const int i0 = chunk * kKeysPerBlock, i1 = min(N, i0 + kKeysPerBlock);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
         const float wi = w[(size_t)row * w_rs + i];
         const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)(unsigned)row << 32) | (unsigned)i));
         const float u = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-08f;  // (0, 1], 24 bits
         const float e = -__logf(u);                                                      // Exp(1); 0 only for u == 1
         float key = wi > 0.f ? wi / fmaxf(e, 1e-30f) : 0.f;
         key = key < 3.0e38f ? key : 3.0e38f;
-        keys[idx] = __float_as_uint(key);  // non-negative floats order like their bit patterns
+        const unsigned k = __float_as_uint(key);  // non-negative floats order like their bit patterns
+        keys[(size_t)row * N + i] = k;
+        atomicAdd(&hist[k >> 21], 1u);
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2048; e += 256)
+        if (hist[e]) atomicAdd(&hist1[(size_t)row * 2048 + e], hist[e]);
 }
 
 constexpr int kSelThreads = 1024;
@@ -45,14 +56,21 @@ constexpr int kSelWaves = kSelThreads / 64;
 // that contains the need-th largest; returns it and lowers `need` by the elements in larger digits.  All threads call it.
 template <int BITS>
 __device__ unsigned radix_pass(const unsigned *__restrict__ keys, int N, unsigned prefix_mask, unsigned prefix, int shift, unsigned &need,
-                               unsigned *hist, unsigned *bcast) {
+                               unsigned *hist, unsigned *bcast, const unsigned *__restrict__ prefilled = nullptr) {
     constexpr int BINS = 1 << BITS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < BINS; e += kSelThreads) hist[e] = 0;
+    for (int e = tid; e < BINS; e += kSelThreads) hist[e] = prefilled ? prefilled[e] : 0;
     __syncthreads();
-    for (int n = tid; n < N; n += kSelThreads) {
-        const unsigned k = keys[n];
-        if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & (BINS - 1)], 1u);
+    if (!prefilled) {
+        constexpr int UF = 8;  // independent loads in flight per thread (a row is 1.6 MB, L2 resident)
+        for (int n0 = tid; n0 < N; n0 += UF * kSelThreads) {
+            unsigned k[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) k[q] = n0 + q * kSelThreads < N ? keys[n0 + q * kSelThreads] : ~prefix;
+#pragma unroll
+            for (int q = 0; q < UF; ++q)
+                if (n0 + q * kSelThreads < N && (k[q] & prefix_mask) == prefix) atomicAdd(&hist[(k[q] >> shift) & (BINS - 1)], 1u);
+        }
     }
     __syncthreads();
     if (wave == 0) {  // suffix sums from the top: lane l owns bins [l*PER, (l+1)*PER)
@@ -91,8 +109,8 @@ __device__ unsigned radix_pass(const unsigned *__restrict__ keys, int N, unsigne
     return digit;
 }
 
-__global__ __launch_bounds__(kSelThreads) void race_select_kernel(const unsigned *__restrict__ keys_all, long long *__restrict__ out, int N,
-                                                                  int K) {
+__global__ __launch_bounds__(kSelThreads) void race_select_kernel(const unsigned *__restrict__ keys_all, const unsigned *__restrict__ hist1,
+                                                                  long long *__restrict__ out, int N, int K) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned bcast[2];
     __shared__ unsigned wsum[2][kSelWaves];
@@ -100,33 +118,48 @@ __global__ __launch_bounds__(kSelThreads) void race_select_kernel(const unsigned
     const unsigned *keys = keys_all + (size_t)row * N;
     long long *dst = out + (size_t)row * K;
     unsigned need = (unsigned)K;
-    const unsigned d1 = radix_pass<11>(keys, N, 0u, 0u, 21, need, hist, bcast);
+    const unsigned d1 = radix_pass<11>(keys, N, 0u, 0u, 21, need, hist, bcast, hist1 + (size_t)row * 2048);
     const unsigned d2 = radix_pass<11>(keys, N, 0xFFE00000u, d1 << 21, 10, need, hist, bcast);
     const unsigned p2 = (d1 << 21) | (d2 << 10);
     const unsigned d3 = radix_pass<10>(keys, N, 0xFFFFFC00u, p2, 0, need, hist, bcast);
     const unsigned T = p2 | d3;  // the K-th largest key; `need` of the elements equal to it are taken, in index order
-    unsigned run_gt = 0, run_eq = 0;
-    for (int n0 = 0; n0 < N; n0 += kSelThreads) {
-        const int n = n0 + tid;
-        const unsigned k = n < N ? keys[n] : 0u;
-        const bool gt = n < N && k > T, eq = n < N && k == T;
-        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-        if (lane == 0) { wsum[0][wave] = (unsigned)__popcll(bg); wsum[1][wave] = (unsigned)__popcll(be); }
-        __syncthreads();
-        unsigned pre_gt = run_gt, pre_eq = run_eq, tot_gt = 0, tot_eq = 0;
+    // ordered output without per-chunk barriers: every wave owns one contiguous 1/16 of the row, counts its winners,
+    // the sixteen counts are scanned once, then the wave walks its range again and writes at its running offsets
+    const int per_wave = ((N + kSelWaves - 1) / kSelWaves + 63) & ~63;
+    const int w0 = wave * per_wave, w1 = min(N, w0 + per_wave);
+    constexpr int UF = 4;
+    unsigned cnt_gt = 0, cnt_eq = 0;
+    for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
+        unsigned k[UF];
 #pragma unroll
-        for (int w2 = 0; w2 < kSelWaves; ++w2) {
-            const unsigned g = wsum[0][w2], e = wsum[1][w2];
-            if (w2 < wave) { pre_gt += g; pre_eq += e; }
-            tot_gt += g; tot_eq += e;
+        for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+#pragma unroll
+        for (int q = 0; q < UF; ++q) {
+            const bool in = n0 + 64 * q < w1;
+            cnt_gt += (unsigned)__popcll(__ballot(in && k[q] > T));
+            cnt_eq += (unsigned)__popcll(__ballot(in && k[q] == T));
         }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        pre_gt += (unsigned)__popcll(bg & below);
-        pre_eq += (unsigned)__popcll(be & below);
-        if (gt || (eq && pre_eq < need)) dst[pre_gt + (pre_eq < need ? pre_eq : need)] = n;
-        run_gt += tot_gt;
-        run_eq += tot_eq;
-        __syncthreads();
+    }
+    if (lane == 0) { wsum[0][wave] = cnt_gt; wsum[1][wave] = cnt_eq; }
+    __syncthreads();
+    unsigned run_gt = 0, run_eq = 0;
+    for (int w2 = 0; w2 < wave; ++w2) { run_gt += wsum[0][w2]; run_eq += wsum[1][w2]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
+        unsigned k[UF];
+#pragma unroll
+        for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+#pragma unroll
+        for (int q = 0; q < UF; ++q) {
+            const int n = n0 + 64 * q;
+            const bool in = n < w1;
+            const bool gt = in && k[q] > T, eq = in && k[q] == T;
+            const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+            const unsigned pre_gt = run_gt + (unsigned)__popcll(bg & below), pre_eq = run_eq + (unsigned)__popcll(be & below);
+            if (gt || (eq && pre_eq < need)) dst[pre_gt + (pre_eq < need ? pre_eq : need)] = n;
+            run_gt += (unsigned)__popcll(bg);
+            run_eq += (unsigned)__popcll(be);
+        }
     }
 }
 
@@ -137,13 +170,16 @@ GFN_EXPORT int gfn_sample_without_replacement(const float *weights, int64_t row_
     if (!weights || !out || !scratch || Bt < 0 || N <= 0 || K <= 0 || row_stride < N)
         return gfn::fail(GFN_ERR_INVALID_ARG, "sample_without_replacement: bad argument");
     if (K > N) return gfn::fail(GFN_ERR_INVALID_ARG, "sample_without_replacement: cannot draw %d of %d without replacement", K, N);
+    if ((long)Bt * ((N + kKeysPerBlock - 1) / kKeysPerBlock) > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "sample_without_replacement: too large");
     if (Bt == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
     unsigned *keys = reinterpret_cast<unsigned *>(scratch);
-    const long total = (long)Bt * N;
-    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(race_keys_kernel, dim3(grid), dim3(256), 0, s, weights, (long)row_stride, keys, Bt, N, seed);
+    unsigned *hist1 = keys + (size_t)Bt * N;
+    if (hipMemsetAsync(hist1, 0, sizeof(unsigned) * 2048 * (size_t)Bt, s) != hipSuccess)
+        return gfn::fail(GFN_ERR_LAUNCH, "sample_without_replacement: memset failed");
+    const int bpr = (N + kKeysPerBlock - 1) / kKeysPerBlock;
+    hipLaunchKernelGGL(race_keys_kernel, dim3((unsigned)(Bt * bpr)), dim3(256), 0, s, weights, (long)row_stride, keys, hist1, N, bpr, seed);
     if (int e = gfn::check_launch("race_keys_kernel")) return e;
-    hipLaunchKernelGGL(race_select_kernel, dim3(Bt), dim3(kSelThreads), 0, s, keys, reinterpret_cast<long long *>(out), N, K);
+    hipLaunchKernelGGL(race_select_kernel, dim3(Bt), dim3(kSelThreads), 0, s, keys, hist1, reinterpret_cast<long long *>(out), N, K);
     return gfn::check_launch("race_select_kernel");
 }

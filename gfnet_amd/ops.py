@@ -261,7 +261,7 @@ def sample_without_replacement(weights, num_samples, seed=None):
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     out = torch.empty((Bt, K), device=dev, dtype=torch.int64)
-    scratch = torch.empty((Bt, N), device=dev, dtype=torch.int32)
+    scratch = torch.empty((Bt * (N + 2048),), device=dev, dtype=torch.int32)
     check(_L().gfn_sample_without_replacement(ptr(w), N, ptr(out), ptr(scratch), Bt, N, K, int(seed) & (2 ** 64 - 1), stream_ptr(dev)),
           "gfn_sample_without_replacement")
     return out

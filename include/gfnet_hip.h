@@ -185,7 +185,7 @@ int gfn_balance_weights(const float *density, float *p, int64_t n, float min_den
  * GFNet.sample (model/network.py:400-402, 411-413).  Exponential race like torch's implementation (key = w / Exp(1),
  * the num_samples largest keys win) with a counter-based generator: same distribution, its own random stream, the same
  * result for the same seed.  weights (Bt,N) with row stride row_stride (non-negative; zero-weight entries are drawn only
- * when fewer than K positive ones exist), out (Bt,K) int64 indices in increasing order, scratch: Bt*N ints. */
+ * when fewer than K positive ones exist), out (Bt,K) int64 indices in increasing order, scratch: Bt*(N + 2048) ints. */
 int gfn_sample_without_replacement(const float *weights, int64_t row_stride, int64_t *out, int *scratch, int Bt, int N, int K,
                                    uint64_t seed, gfn_stream_t stream);
 
