@@ -27,6 +27,7 @@ _SIGNATURES = {
     "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
     "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_flow_update_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],
+    "gfn_flow_update_out_fwd": [c_vp] * 5 + [c_i64, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_match_post_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_int] * 4 + [c_vp],
     "gfn_kde_msplit": [c_int, c_int, c_int],
     "gfn_kde_density": [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64, c_i64, c_double, c_vp, c_i64, c_vp],

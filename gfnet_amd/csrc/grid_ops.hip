@@ -238,16 +238,18 @@ __global__ __launch_bounds__(256) void interp_bilinear_kernel(const float *__res
     }
 }
 
-// delta: (B, >=3, G, G) refiner output (channels 0,1 = displacement, 2 = certainty), batch stride delta_bs.
-__global__ __launch_bounds__(256) void flow_update_kernel(float *__restrict__ flow, float *__restrict__ cert,
-                                                          const float *__restrict__ delta, long delta_bs,
-                                                          float *__restrict__ disp_prev, int B, int G, float scale,
-                                                          float div_x, float div_y, int zero_small, int first) {
+// dflow: (B, >=2, G, G) displacement increment with batch stride dflow_bs, dcert: (B, >=1, G, G) certainty increment with
+// dcert_bs (the refiner's two outputs; one (B,3,G,G) tensor or two).  flow_in/cert_in -> flow_out/cert_out (may alias).
+__global__ __launch_bounds__(256) void flow_update_kernel(const float *__restrict__ flow_in, const float *__restrict__ cert_in,
+                                                          float *flow_out, float *cert_out, const float *__restrict__ dflow,
+                                                          long dflow_bs, const float *__restrict__ dcert, long dcert_bs,
+                                                          float *__restrict__ disp_prev, int B, int G, float scale, float div_x,
+                                                          float div_y, int zero_small, int first) {
     const long GG = (long)G * G, total = (long)B * GG;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int b = (int)(idx / GG);
         const long r = idx - (long)b * GG;
-        const float *dl = delta + (size_t)b * delta_bs + r;
+        const float *dl = dflow + (size_t)b * dflow_bs + r;
         float dx = scale * (dl[0] / div_x), dy = scale * (dl[GG] / div_y);  // network.py:262-263
         float *pp = disp_prev + (size_t)b * 2 * GG + r;
         if (zero_small) {  // network.py:256,264-265
@@ -257,10 +259,10 @@ __global__ __launch_bounds__(256) void flow_update_kernel(float *__restrict__ fl
         }
         pp[0] = dx;
         pp[GG] = dy;
-        float *fl = flow + (size_t)b * 2 * GG + r;
-        fl[0] += dx;
-        fl[GG] += dy;
-        cert[idx] += dl[2 * GG];
+        const size_t o = (size_t)b * 2 * GG + r;
+        flow_out[o] = flow_in[o] + dx;
+        flow_out[o + GG] = flow_in[o + GG] + dy;
+        cert_out[idx] = cert_in[idx] + dcert[(size_t)b * dcert_bs + r];
     }
 }
 
@@ -362,9 +364,23 @@ GFN_EXPORT int gfn_flow_update_fwd(float *flow, float *certainty, const float *d
     if (!flow || !certainty || !delta || !disp_prev || B < 0 || G <= 0 || W0 <= 0 || H0 <= 0 || delta_bs < 3L * G * G)
         return gfn::fail(GFN_ERR_INVALID_ARG, "flow_update: bad argument");
     if (B == 0) return GFN_OK;
-    hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((long)B * G * G)), dim3(256), 0, (hipStream_t)stream, flow,
-                       certainty, delta, (long)delta_bs, disp_prev, B, G, (float)scale, (float)(4 * W0), (float)(4 * H0),
-                       zero_small, first_iteration);
+    hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((long)B * G * G)), dim3(256), 0, (hipStream_t)stream, flow, certainty, flow,
+                       certainty, delta, (long)delta_bs, delta + 2L * G * G, (long)delta_bs, disp_prev, B, G, (float)scale,
+                       (float)(4 * W0), (float)(4 * H0), zero_small, first_iteration);
+    return gfn::check_launch("flow_update_kernel");
+}
+
+GFN_EXPORT int gfn_flow_update_out_fwd(const float *flow_in, const float *cert_in, float *flow_out, float *cert_out,
+                                       const float *dflow, int64_t dflow_bs, const float *dcert, int64_t dcert_bs, float *disp_prev,
+                                       int B, int G, int scale, int W0, int H0, int zero_small, int first_iteration,
+                                       gfn_stream_t stream) {
+    if (!flow_in || !cert_in || !flow_out || !cert_out || !dflow || !dcert || !disp_prev || B < 0 || G <= 0 || W0 <= 0 || H0 <= 0 ||
+        dflow_bs < 2L * G * G || dcert_bs < (long)G * G)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "flow_update_out: bad argument");
+    if (B == 0) return GFN_OK;
+    hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((long)B * G * G)), dim3(256), 0, (hipStream_t)stream, flow_in, cert_in, flow_out,
+                       cert_out, dflow, (long)dflow_bs, dcert, (long)dcert_bs, disp_prev, B, G, (float)scale, (float)(4 * W0),
+                       (float)(4 * H0), zero_small, first_iteration);
     return gfn::check_launch("flow_update_kernel");
 }
 

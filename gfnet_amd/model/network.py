@@ -238,10 +238,9 @@ class GFNet(nn.Module):
             disp_prev = torch.empty_like(flow)
             for itr in range(num_itr[idx]):
                 d_flow, d_cert, _ = self.conv_refiner[scale](num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
-                delta = torch.cat((d_flow.float(), d_cert.float()), dim=1)
-                flow, certainty = flow.clone(), certainty.clone()  # each iteration's result is kept (corresps)
-                ops.flow_update_(flow, certainty, delta, disp_prev, int(scale), W0, H0, zero_small=not self.training,
-                                 first_iteration=(itr == 0))                                     # :262-268
+                # each iteration's result is kept (corresps): out-of-place update straight from the refiner's outputs
+                flow, certainty = ops.flow_update(flow, certainty, d_flow, d_cert, disp_prev, int(scale), W0, H0,
+                                                  zero_small=not self.training, first_iteration=(itr == 0))  # :262-268
                 corresps[scale][itr + 1] = {"flow": flow, "certainty": certainty}
             if scale != "1":                                                                      # :271-281
                 flow = ops.interpolate_bilinear(flow, num_grid[idx + 1])

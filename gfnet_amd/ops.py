@@ -148,6 +148,34 @@ def flow_update_(flow, certainty, delta, disp_prev, scale, W0, H0, zero_small=Tr
     return flow, certainty
 
 
+def _plane_view(t, planes, G):
+    """(tensor, batch stride) of a (B, >=planes, G, G) fp32 tensor whose planes are contiguous (a channel slice is fine)."""
+    if t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(2) == G and t.stride(1) == G * G:
+        return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * G * G)
+    t = f32c(t)
+    return t, t.shape[1] * G * G
+
+
+def flow_update(flow, certainty, d_flow, d_cert, disp_prev, scale, W0, H0, zero_small=True, first_iteration=True):
+    """model/network.py:262-268 out of place: returns (flow + displacement(d_flow), certainty + d_cert) as new tensors (the
+    reference keeps every iteration's result); d_flow (B,2,G,G) / d_cert (B,1,G,G) may be channel slices of one tensor."""
+    dev = require_gpu(flow, certainty, d_flow, d_cert, disp_prev)
+    B, _, G, _ = flow.shape
+    if tuple(certainty.shape) != (B, 1, G, G) or tuple(disp_prev.shape) != (B, 2, G, G) or tuple(d_flow.shape) != (B, 2, G, G) or \
+            tuple(d_cert.shape) != (B, 1, G, G):
+        raise ValueError("flow_update: inconsistent shapes")
+    if disp_prev.dtype != torch.float32 or not disp_prev.is_contiguous():
+        raise ValueError("flow_update: disp_prev must be contiguous fp32 (updated in place)")
+    fi, ci = f32c(flow), f32c(certainty)
+    df, df_bs = _plane_view(d_flow, 2, G)
+    dc, dc_bs = _plane_view(d_cert, 1, G)
+    fo, co = torch.empty_like(fi), torch.empty_like(ci)
+    check(_L().gfn_flow_update_out_fwd(ptr(fi), ptr(ci), ptr(fo), ptr(co), c_vp(df.data_ptr()), df_bs, c_vp(dc.data_ptr()), dc_bs,
+                                       ptr(disp_prev), B, G, int(scale), int(W0), int(H0), 1 if zero_small else 0,
+                                       1 if first_iteration else 0, stream_ptr(dev)), "gfn_flow_update_out_fwd")
+    return fo, co
+
+
 def match_post(flow, certainty, cert16=None, symmetric=True):
     """model/network.py:332-338 + 358-384: returns warp (B,G,2G,4)/(B,G,G,4) and certainty (B,G,2G)/(B,G,G)."""
     dev = require_gpu(flow, certainty, cert16)

@@ -141,6 +141,12 @@ int gfn_interp_bilinear_fwd(const float *in, float *out, int BC, int H, int W, i
  * flow (B,2,G,G), certainty (B,1,G,G), delta (B,>=3,G,G) with batch stride delta_bs, disp_prev (B,2,G,G). */
 int gfn_flow_update_fwd(float *flow, float *certainty, const float *delta, int64_t delta_bs, float *disp_prev, int B, int G,
                         int scale, int W0, int H0, int zero_small, int first_iteration, gfn_stream_t stream);
+/* The same step out of place and with the refiner's two outputs as they come (network.py:259-268 keeps every iteration's
+ * flow and certainty): flow_out = flow_in + disp(dflow), cert_out = cert_in + dcert; dflow (B,>=2,G,G) with batch stride
+ * dflow_bs, dcert (B,>=1,G,G) with dcert_bs.  Outputs may alias the inputs. */
+int gfn_flow_update_out_fwd(const float *flow_in, const float *cert_in, float *flow_out, float *cert_out, const float *dflow,
+                            int64_t dflow_bs, const float *dcert, int64_t dcert_bs, float *disp_prev, int B, int G, int scale,
+                            int W0, int H0, int zero_small, int first_iteration, gfn_stream_t stream);
 
 /* match() post-processing -- model/network.py:332-338 + 358-384.
  *   flow (nb,2,G,G), certainty (nb,1,G,G) finest-scale logits, nb = 2*B_images when symmetric;

@@ -159,6 +159,17 @@ def test_flow_update_vs_oracle():
     assert np.all(d2 == 0)
     assert_close(host(tp), d2, 1e-6, "disp 2")
     assert_close(host(tf), f2, 1e-6, "flow 2")
+    # out-of-place form on channel slices of one refiner output and on two separate tensors: same numbers, inputs untouched
+    td = dev(delta)
+    tf0, tc0, tp0 = dev(flow), dev(cert), torch.zeros(B, 2, G, G, device="cuda")
+    fo, co = ops.flow_update(tf0, tc0, td[:, :2], td[:, 2:3], tp0, 8, 448, 448, zero_small=True, first_iteration=True)
+    assert_close(host(fo), f1, 1e-6, "flow (out of place)")
+    assert_close(host(co), c1, 1e-6, "cert (out of place)")
+    np.testing.assert_array_equal(host(tf0), flow)
+    np.testing.assert_array_equal(host(tc0), cert)
+    tp1 = torch.zeros(B, 2, G, G, device="cuda")
+    fo2, co2 = ops.flow_update(tf0, tc0, td[:, :2].contiguous(), td[:, 2:3].contiguous(), tp1, 8, 448, 448, first_iteration=True)
+    assert torch.equal(fo, fo2) and torch.equal(co, co2) and torch.equal(tp0, tp1)
 
 
 @pytest.mark.parametrize("tag,symmetric,attenuate", [("sym_up_att", True, True), ("plain", False, False),
