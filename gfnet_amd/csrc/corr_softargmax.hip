@@ -46,22 +46,65 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__res
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int c = 2 * s + h;
-        bop[s] = (c < C) ? f0b[(size_t)c * N0 + ic] : 0.f;
+        const float v = f0b[(size_t)min(c, C - 1) * N0 + ic];
+        bop[s] = c < C ? v : 0.f;
     }
 
     const float x_lo = (float)(-1 + 1.0 / W1), x_hi = (float)(1 - 1.0 / W1);
     const float y_lo = (float)(-1 + 1.0 / H1), y_hi = (float)(1 - 1.0 / H1);
     const float inv_w1 = 1.0f / (float)W1;
     float m = -INFINITY, l = 0.f, ax = 0.f, ay = 0.f;
+    const bool row_tiles = W1 == 32;                       // wave-uniform
+    const float e_scale = 1.4426950408889634f / sqrt_c;    // exp(v / sqrt(C)) = exp2(v * log2(e) / sqrt(C))
+    float gx16[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gx16[r] = gfn::linspace_at(x_lo, x_hi, W1, min((r & 3) + 8 * (r >> 2) + 4 * h, W1 - 1));
 
-    for (int j0 = 0; j0 < N1; j0 += 32) {
+    // A operand of one tile (32 B-positions x all channels): loads are branch-free (clamped address) so the
+    // compiler batches them, and the next tile's operand is requested before this tile's MFMA chain starts -- with two
+    // waves per SIMD nothing else hides the L2 latency.
+    auto load_tile = [&](float (&a)[KS], int j0) {
         const int jl = min(j0 + col, N1 - 1);
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int c = 2 * s + h;
-            const float a = (c < C) ? f1b[(size_t)c * N1 + jl] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bop[s], acc, 0, 0, 0);
+            a[s] = f1b[(size_t)min(2 * s + h, C - 1) * N1 + jl];  // channels >= C meet a zero in bop
+        }
+    };
+    float a_cur[KS], a_nxt[KS];
+    load_tile(a_cur, 0);
+    // land the first tile before the loop: otherwise the wait-count pass assumes 64 loads in flight at the loop head and
+    // makes every MFMA of every tile wait for the *prefetch* it was meant to overlap with
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a_cur[s]));
+    for (int j0 = 0; j0 < N1; j0 += 32) {
+        if (j0 + 32 < N1) load_tile(a_nxt, j0 + 32);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bop[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
+        if (WRITE_FLOW && !WRITE_VOL && row_tiles) {
+            // W1 == 32: a tile of 32 B-positions is one grid row -- its y coordinate is wave-uniform, the 16 x coordinates of
+            // this lane's accumulator rows never change, and the 1/sqrt(C) scale folds into the exponent.  ~6 VALU
+            // instructions per value instead of ~40: the kernel was VALU-bound (the fp32 MFMA shares the vector ALUs).
+            float mt = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
+            const float mn = fmaxf(m, mt);
+            const float sc = __builtin_amdgcn_exp2f((m - mn) * e_scale);  // m = -inf on the first tile -> 0
+            float lt = 0.f, axt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f((acc[r] - mn) * e_scale);
+                lt += e;
+                axt = fmaf(e, gx16[r], axt);
+            }
+            const float gy = gfn::linspace_at(y_lo, y_hi, H1, j0 >> 5);
+            l = fmaf(l, sc, lt);
+            ax = fmaf(ax, sc, axt);
+            ay = fmaf(ay, sc, lt * gy);
+            m = mn;
+            continue;
         }
         float sv[16];
         float mt = -INFINITY;
@@ -92,6 +135,7 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__res
             m = mn;
         }
     }
+    if (WRITE_FLOW && !WRITE_VOL && row_tiles) m = m / sqrt_c;  // the running maximum was kept in unscaled units
     if (WRITE_FLOW) {
         // merge the two half-waves (same column i, disjoint rows j)
         const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
