@@ -40,8 +40,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file flags.  kde.hip: MFMA results straight into VGPRs -- every one of them feeds a v_exp_f32, which cannot read AGPRs
+FILE_FLAGS = {"kde.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _compile(src, verbose, extra):
     obj = src[:-4] + ".o"
+    extra = list(extra) + FILE_FLAGS.get(os.path.basename(src), [])
     if _stale(obj, _deps(src)):
         cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:

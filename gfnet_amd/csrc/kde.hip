@@ -345,6 +345,14 @@ __global__ __launch_bounds__(256) void kde4_operands_kernel(const float *__restr
 // One wave = 64 queries (two 32-row tiles); reference blocks of 64 points (two 32-column tiles) culled by their
 // bounding boxes as in kde4_culled_kernel.  Lane (col = lane&31, kh = lane>>5) accumulates its column of every tile;
 // the 32 columns are summed across lanes once at the end.
+//   * the cull runs 64 blocks at a time: lane L tests block base+L against the wave's query box, one ballot gives the
+//     survivor mask, and the wave then walks the set bits (the per-block test cost 20 vector instructions and one exposed
+//     L2 round trip for each of the 313 blocks of a 20000-point row; now 5 of each);
+//   * the operands of the next surviving block are requested before the current block's MFMAs issue;
+//   * both column tiles' MFMAs are issued before the first exponential, so the matrix pipe works under the v_exp stream;
+//   * this file is compiled with -amdgpu-mfma-vgpr-form: the products land in VGPRs, not in AGPRs that cost one
+//     v_accvgpr_read per exponential (build.py).
+// What bounds the kernel is v_exp_f32 (quarter rate: 16 cycles per wave instruction) on the surviving pairs.
 __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__restrict__ xs, const bf16x8 *__restrict__ aop,
                                                                 const bf16x8 *__restrict__ bop, const float *__restrict__ box,
                                                                 float *__restrict__ part, int N, int Mp, int NT, int MT) {
@@ -375,32 +383,57 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__r
     const bf16x8 *ap = aop + ((size_t)bt * NT + (q0 >> 5)) * 128 + kh * 32 + col;
     const bf16x8 a00 = ap[0], a01 = ap[64], a10 = ap[128], a11 = ap[192];  // [row tile][MFMA]
     const bf16x8 *bp = bop + (size_t)bt * MT * 128 + kh * 32 + col;
-    const float *bx = box + (size_t)bt * nblk * 8;
+    const float4 *bx = reinterpret_cast<const float4 *>(box + (size_t)bt * nblk * 8);
     f32x2 acc0[8], acc1[8];  // [r/2] = rows r, r+1 of the lane's column (packed adds)
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc0[r] = f32x2{0.f, 0.f}, acc1[r] = f32x2{0.f, 0.f};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int blk = b0; blk < b1; ++blk) {
-        float d2 = 0.f;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float g = fmaxf(fmaxf(qlo[d] - bx[blk * 8 + 4 + d], bx[blk * 8 + d] - qhi[d]), 0.f);
-            d2 = fmaf(g, g, d2);
+    for (int base = b0; base < b1; base += 64) {
+        bool keep = false;
+        if (base + lane < b1) {
+            const float4 lo = bx[(base + lane) * 2], hi = bx[(base + lane) * 2 + 1];
+            const float g0 = fmaxf(fmaxf(qlo[0] - hi.x, lo.x - qhi[0]), 0.f), g1 = fmaxf(fmaxf(qlo[1] - hi.y, lo.y - qhi[1]), 0.f);
+            const float g2 = fmaxf(fmaxf(qlo[2] - hi.z, lo.z - qhi[2]), 0.f), g3 = fmaxf(fmaxf(qlo[3] - hi.w, lo.w - qhi[3]), 0.f);
+            keep = !(fmaf(g3, g3, fmaf(g2, g2, fmaf(g1, g1, g0 * g0))) > kKdeCutoffLog2);
         }
-        if (d2 > kKdeCutoffLog2) continue;  // the same for every lane of the wave
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const bf16x8 *b = bp + (size_t)(blk * 2 + ct) * 128;
-            const bf16x8 bv0 = b[0], bv1 = b[64];
-            f32x16 e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, bv0, zero16, 0, 0, 0);
-            f32x16 e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, bv0, zero16, 0, 0, 0);
-            e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, bv1, e0, 0, 0, 0);
-            e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, bv1, e1, 0, 0, 0);
+        unsigned long long mask = __ballot(keep);
+        if (!mask) continue;
+        bf16x8 c0, c1, c2, c3;  // [column tile][MFMA] of the current block
+        {
+            const bf16x8 *b = bp + (size_t)(base + __builtin_ctzll(mask)) * 256;
+            mask &= mask - 1;
+            c0 = b[0], c1 = b[64], c2 = b[128], c3 = b[192];
+        }
+        // land the first block here: otherwise every MFMA of the loop is made to wait for the prefetch as well
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        while (true) {
+            const bool more = mask != 0;
+            bf16x8 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (more) {
+                const bf16x8 *b = bp + (size_t)(base + __builtin_ctzll(mask)) * 256;
+                mask &= mask - 1;
+                n0 = b[0], n1 = b[64], n2 = b[128], n3 = b[192];
+            }
+            f32x16 e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c0, zero16, 0, 0, 0);
+            f32x16 e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c0, zero16, 0, 0, 0);
+            e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c1, e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c1, e1, 0, 0, 0);
+            f32x16 f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c2, zero16, 0, 0, 0);
+            f32x16 f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c2, zero16, 0, 0, 0);
+            f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c3, f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c3, f1, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 acc0[r] += f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
                 acc1[r] += f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
             }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc0[r] += f32x2{__builtin_amdgcn_exp2f(-f0[2 * r]), __builtin_amdgcn_exp2f(-f0[2 * r + 1])};
+                acc1[r] += f32x2{__builtin_amdgcn_exp2f(-f1[2 * r]), __builtin_amdgcn_exp2f(-f1[2 * r + 1])};
+            }
+            if (!more) break;
+            c0 = n0, c1 = n1, c2 = n2, c3 = n3;
         }
     }
     // sum the 32 columns (lanes with the same kh), then lanes col == 0 hold rows (r&3) + 8(r>>2) + 4kh of each row tile
