@@ -76,7 +76,10 @@ __device__ __forceinline__ BilinC bilin_clamped(float gx, float gy, int W, int H
 }
 
 // One thread per (direction, grid cell): both bilinear set-ups once, then the channels in groups of
-// 8 with all 32 gathers of a group in flight; stores run along the grid row for every channel.
+// 8 with all 64 gathers of a group in flight; stores run along the grid row for every channel.
+// A workgroup never straddles two directions (blockIdx.y = direction), so every plane base is a scalar and a load is
+// "scalar base + 32-bit lane offset": no 64-bit address arithmetic per gather (it was 2 of every 5 vector instructions
+// and pushed the kernel to 178 VGPRs = 2 waves per SIMD).
 // Symmetric batches are virtual: direction b < Bh queries image A[b] against B[b], direction
 // b >= Bh queries B[b-Bh] against A[b-Bh] (the reference concatenates the pyramids instead,
 // model/network.py:213-222).
@@ -85,50 +88,51 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
                                                             const float *__restrict__ db, float *__restrict__ d, long d_bs,
                                                             int B, int Bh, int C, int Hs, int Ws, int G, int Dd,
                                                             float disp_scale) {
-    const long total = (long)B * G * G;
     const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
-    const size_t plane = (size_t)Hs * Ws, GG = (size_t)G * G;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % G);
-        const long t = idx / G;
-        const int i = (int)(t % G);
-        const int b = (int)(t / G);
-        const float *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
-        const float *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
-        const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
-        const float fx = flow[(((size_t)b * 2 + 0) * G + i) * G + j], fy = flow[(((size_t)b * 2 + 1) * G + i) * G + j];
-        const BilinC sa = bilin_clamped(cx, cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
-        const BilinC sb = bilin_clamped(fx, fy, Ws, Hs);  // x_hat = grid_sample(y, flow)                 network.py:537
-        float *o = d + (size_t)b * d_bs + (size_t)i * G + j;
-        for (int c0 = 0; c0 < C; c0 += 8) {
-            float va[8][4], vb[8][4];
+    const unsigned plane = (unsigned)(Hs * Ws), GG = (unsigned)(G * G);
+    const int b = blockIdx.y;
+    const unsigned cell = blockIdx.x * 256u + threadIdx.x;
+    if (cell >= GG) return;
+    const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
+    const float *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
+    const float *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
+    const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
+    const float *fl = flow + (size_t)b * 2 * GG;
+    const float fx = fl[cell], fy = fl[GG + cell];
+    const BilinC sa = bilin_clamped(cx, cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
+    const BilinC sb = bilin_clamped(fx, fy, Ws, Hs);  // x_hat = grid_sample(y, flow)                 network.py:537
+    unsigned oa[4], ob[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const size_t pl = (size_t)min(c0 + k, C - 1) * plane;
+    for (int e = 0; e < 4; ++e) oa[e] = (unsigned)sa.o[e], ob[e] = (unsigned)sb.o[e];
+    float *o = d + (size_t)b * d_bs;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float va[8][4], vb[8][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    va[k][e] = q[pl + sa.o[e]];
-                    vb[k][e] = sm[pl + sb.o[e]];
-                }
-            }
+        for (int k = 0; k < 8; ++k) {
+            const float *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (c0 + k < C) {
-                    float ra = 0.f, rb = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ra += va[k][e] * sa.w[e];
-                        rb += vb[k][e] * sb.w[e];
-                    }
-                    o[(size_t)(c0 + k) * GG] = ra;
-                    o[(size_t)(C + c0 + k) * GG] = rb;
-                }
+            for (int e = 0; e < 4; ++e) {
+                va[k][e] = qp[oa[e]];
+                vb[k][e] = sp[ob[e]];
             }
         }
-        // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
-        const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
-        for (int k = 0; k < Dd; ++k) o[(size_t)(2 * C + k) * GG] = dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (c0 + k < C) {
+                float ra = 0.f, rb = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ra += va[k][e] * sa.w[e];
+                    rb += vb[k][e] * sb.w[e];
+                }
+                (o + (size_t)(c0 + k) * GG)[cell] = ra;
+                (o + (size_t)(C + c0 + k) * GG)[cell] = rb;
+            }
+        }
     }
+    // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
+    const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
+    for (int k = 0; k < Dd; ++k) (o + (size_t)(2 * C + k) * GG)[cell] = dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k];
 }
 
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
@@ -315,8 +319,8 @@ GFN_EXPORT int gfn_refiner_input_fwd(const float *f0, const float *f1, const flo
         (symmetric && (B & 1)) || (long)C * Hs * Ws >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
     if (B == 0) return GFN_OK;
-    const long total = (long)B * G * G;
-    hipLaunchKernelGGL(refiner_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, f0, f1, flow, disp_w,
+    if (B > 65535 || (long)G * G >= (1L << 31)) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: batch > 65535 or grid too large");
+    hipLaunchKernelGGL(refiner_input_kernel, dim3((unsigned)(((long)G * G + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, flow, disp_w,
                        disp_b, d, (long)d_bs, B, symmetric ? B / 2 : B, C, Hs, Ws, G, disp_dim, disp_scale);
     return gfn::check_launch("refiner_input_kernel");
 }
