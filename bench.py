@@ -90,7 +90,7 @@ class StandInRefiner(nn.Module):
     """The HIP part of ConvRefiner.forward (network.py:533-558) followed by a stand-in for the conv
     stack (network.py:560-563; PyTorch-ROCm/MIOpen, out of scope): like a trained refiner it returns
     the increment that moves the flow onto the true warp (smooth, also outside the overlap) and a
-    constant certainty increment.  Two tiny torch elementwise ops; everything else is the real path."""
+    constant certainty increment.  One tiny torch elementwise op; everything else is the real path."""
 
     def __init__(self, feat, disp, radius, scale, gt, conv_stack="off"):
         super().__init__()
@@ -110,12 +110,15 @@ class StandInRefiner(nn.Module):
             self.inner.conv_precision = conv_stack
         self.conv_stack = conv_stack
         self.scale, self.gt = scale, gt  # gt: {num_grid: (true flow (2B,2,G,G), image size)}
-        self._cert = {}
+        self._cert, self._gtk = {}, {}
 
     def forward(self, num_grid, x, y, flow, scale_factor=1):
         d, lc = self.inner.assemble(num_grid, x, y, flow, scale_factor)
         gt, size = self.gt[num_grid]
-        delta = (gt - flow) * (4.0 * size / self.scale)   # undone by network.py:262-263's scale/(4*W0)
+        k = 4.0 * size / self.scale                       # undone by network.py:262-263's scale/(4*W0)
+        if num_grid not in self._gtk:
+            self._gtk[num_grid] = gt * k
+        delta = torch.add(self._gtk[num_grid], flow, alpha=-k)  # (gt - flow) * k in one launch
         if num_grid not in self._cert:
             self._cert[num_grid] = torch.full((flow.shape[0], 1, num_grid, num_grid), 1.0, device=flow.device)
         cert = self._cert[num_grid]
