@@ -61,7 +61,7 @@ struct LcParams {
     float sqrt_c, inv_sqrt_c;
     int r, win_h, win_w, grid_based;  // general path / flagged cells
     float win_xhi, win_yhi;           // tiled path: linspace end points 2r/W, 2r/H rounded to fp32
-    int *todo;                        // [1 + B*tiles]: count, then ids of tiles left to the irregular launch
+    int *todo;                        // [2 + B*tiles]: count, queue head of the second launch, then ids of tiles left to it
     long todo_ints;
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
@@ -127,15 +127,32 @@ __device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, in
     const float *f1p = f1_of(p, b);
     const size_t plane = (size_t)p.H * p.W, cs = (size_t)p.G * p.G;
     const long o00 = (long)y0 * p.W + x0;
+    // zero padding without branches: a corner outside the image reads pixel 0 with weight 0 (adds an exact 0), so the
+    // gathers of 8 channels can all be in flight at once -- the branchy form exposed one L2 round trip per channel
+    const long oa = (ya & xa) ? o00 : 0, ob = (ya & xb) ? o00 + 1 : 0, oc = (yb & xa) ? o00 + p.W : 0, od = (yb & xb) ? o00 + p.W + 1 : 0;
+    const float wa = (ya & xa) ? w00 : 0.f, wb = (ya & xb) ? w01 : 0.f, wc = (yb & xa) ? w10 : 0.f, wd = (yb & xb) ? w11 : 0.f;
     float acc = 0.f;
-    for (int c = 0; c < p.C; ++c) {
-        const float *pl = f1p + c * plane;
-        float s = 0.f;
-        if (ya & xa) s += pl[o00] * w00;
-        if (ya & xb) s += pl[o00 + 1] * w01;
-        if (yb & xa) s += pl[o00 + p.W] * w10;
-        if (yb & xb) s += pl[o00 + p.W + 1] * w11;
-        acc += (f0p[c * cs] / p.sqrt_c) * s;
+    constexpr int UC = 8;
+    for (int c0 = 0; c0 < p.C; c0 += UC) {
+        float va[UC], vb[UC], vc[UC], vd[UC], q[UC];
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+            const int c = min(c0 + u, p.C - 1);
+            const float *pl = f1p + c * plane;
+            va[u] = pl[oa]; vb[u] = pl[ob]; vc[u] = pl[oc]; vd[u] = pl[od];
+            q[u] = f0p[c * cs];
+        }
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+            if (c0 + u < p.C) {
+                float s = 0.f;
+                s += va[u] * wa;
+                s += vb[u] * wb;
+                s += vc[u] * wc;
+                s += vd[u] * wd;
+                acc += (q[u] / p.sqrt_c) * s;
+            }
+        }
     }
     return acc;
 }
@@ -434,9 +451,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     if (STAGED && (long)u.pitch * u.h > kCapSlots) {
         // strong magnification / rotation / scattered flow: the windows do not fit the stage
         if (!SECOND) {
-            if (tid == 0) p.todo[1 + atomicAdd(p.todo, 1)] = (int)wid;
+            if (tid == 0) p.todo[2 + atomicAdd(p.todo, 1)] = (int)wid;
         } else {
             __syncthreads();
+            if (ABL(p, 1024)) return;
             process_tile<R, ROUNDS, false, TW, true>(p, b, row0, col0, rows, wid, smem);  // gather from L2
         }
         return;
@@ -529,21 +547,35 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             } else {
                 const size_t plane = (size_t)H * W;
                 const int cX0 = cellX0[rd * 32 + cr], cY0 = cellY0[rd * 32 + cr];
+                // TG patch positions x 16 channels = 64 gathers in flight per lane: this path is pure L2 latency
+                // (one position at a time left a sub-tile of scattered flow at 150-200 us)
+                constexpr int TG = 4;
 #pragma unroll
-                for (int t = 0; t < NP; ++t) {
-                    const int pp = s16 + 16 * t;
-                    const int yy = pp / PW, xx = pp - yy * PW;
-                    const int X = cX0 + xx, Y = cY0 + yy;
-                    const bool in = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
-                    const float *src = f1c + (in ? (size_t)Y * W + X : 0);  // offset 0 when outside: valid memory, masked below
-                    float v[kChunk];
+                for (int t0 = 0; t0 < NP; t0 += TG) {
+                    float v[TG][kChunk];
+                    bool in[TG];
 #pragma unroll
-                    for (int k = 0; k < kChunk; ++k) v[k] = src[k * plane];
-                    float a = acc[rd][t];
+                    for (int tt = 0; tt < TG; ++tt) {
+                        if (t0 + tt < NP) {
+                            const int pp = s16 + 16 * (t0 + tt);
+                            const int yy = pp / PW, xx = pp - yy * PW;
+                            const int X = cX0 + xx, Y = cY0 + yy;
+                            in[tt] = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
+                            const float *src = f1c + (in[tt] ? (size_t)Y * W + X : 0);  // offset 0 when outside: valid memory, masked below
 #pragma unroll
-                    for (int k = 0; k < kChunk; ++k) a = fmaf(f[k], in ? v[k] : 0.f, a);
-                    acc[rd][t] = a;
-                    __builtin_amdgcn_sched_barrier(0);  // one pass of loads in flight at a time (register budget)
+                            for (int k = 0; k < kChunk; ++k) v[tt][k] = src[k * plane];
+                        }
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < TG; ++tt) {
+                        if (t0 + tt < NP) {
+                            float a = acc[rd][t0 + tt];
+#pragma unroll
+                            for (int k = 0; k < kChunk; ++k) a = fmaf(f[k], in[tt] ? v[tt][k] : 0.f, a);
+                            acc[rd][t0 + tt] = a;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one group of loads in flight at a time (register budget)
                 }
             }
         }
@@ -652,13 +684,21 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
 #endif
     // ---- flagged cells: general per-tap routine (about one cell in 10^4) ------------------------
     if (*nSlow != 0 && !ABL(p, 16)) {  // block-uniform, rare
-        for (int cell = 0; cell < NC; ++cell) {
-            if (!cellSlow[cell]) continue;
+        // compact the flagged cells (cellX0 is free now), then spread (cell, tap) pairs over the whole workgroup
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int cell = 0; cell < NC; ++cell)
+                if (cellSlow[cell] && cell_ok(cell)) cellX0[n++] = cell;
+            *nSlow = n;
+        }
+        __syncthreads();
+        const int total = *nSlow * K;
+        for (int e = tid; e < total; e += kThreads) {
+            const int cell = cellX0[e / K], k = e % K;
             const int gi = cell_gi(cell), gj = cell_gj(cell);
-            if (!cell_ok(cell)) continue;
-            for (int k = tid; k < K; k += kThreads)
-                p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
-                    tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
+            p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
+                tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
         }
     }
 }
@@ -692,13 +732,19 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
     constexpr int SUBS = (TH / SH) * (kTileW / 8);
     const int n = p.todo[0] * SUBS;
     const int tiles = p.tiles_x * p.tiles_y;
-    for (int it = blockIdx.x; it < n; it += gridDim.x) {
-        const unsigned wid = (unsigned)p.todo[1 + it / SUBS];
+    // work items differ by 10x (a staged sub-tile vs one that gathers from L2): hand them out first come, first served
+    __shared__ int next_item;
+    while (true) {
+        if (threadIdx.x == 0) next_item = atomicAdd(p.todo + 1, 1);
+        __syncthreads();
+        const int it = next_item;
+        if (it >= n) break;
+        const unsigned wid = (unsigned)p.todo[2 + it / SUBS];
         const int sub = it % SUBS;
         const int b = wid / tiles, tile = wid - b * tiles;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         process_tile<R, 1, true, 8, true>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
-        __syncthreads();  // LDS is reused by the next sub-tile
+        __syncthreads();  // LDS (and next_item) are reused by the next sub-tile
     }
 }
 
@@ -724,8 +770,8 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
         attr_set = true;
     }
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
-    if ((size_t)p.todo_ints < (size_t)total + 1) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    if (hipMemsetAsync(p.todo, 0, sizeof(int), stream) != hipSuccess) return gfn::fail(GFN_ERR_LAUNCH, "local_corr: memset failed");
+    if ((size_t)p.todo_ints < (size_t)total + 2) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
+    if (hipMemsetAsync(p.todo, 0, 2 * sizeof(int), stream) != hipSuccess) return gfn::fail(GFN_ERR_LAUNCH, "local_corr: memset failed");
     hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(total), dim3(kThreads), lds, stream, p);
     if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
     const unsigned grid2 = total < 512 ? total : 512;
@@ -739,7 +785,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
 GFN_EXPORT int64_t gfn_local_corr_scratch_bytes(int B, int G) {
     // smallest tile is 2 x 16 cells -> at most B * ceil(G/2) * ceil(G/16) tiles, plus the counter
     const int64_t tiles = (int64_t)((G + 1) / 2) * ((G + 15) / 16);
-    return 4 * ((int64_t)B * tiles + 1);
+    return 4 * ((int64_t)B * tiles + 2);
 }
 
 GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second,
