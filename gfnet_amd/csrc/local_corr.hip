@@ -560,10 +560,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                             const int pp = s16 + 16 * (t0 + tt);
                             const int yy = pp / PW, xx = pp - yy * PW;
                             const int X = cX0 + xx, Y = cY0 + yy;
-                            in[tt] = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H);
-                            const float *src = f1c + (in[tt] ? (size_t)Y * W + X : 0);  // offset 0 when outside: valid memory, masked below
+                            in[tt] = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H) & !ABL(p, 2048);
+                            const unsigned off = in[tt] ? (unsigned)(Y * W + X) : 0u;  // offset 0 when outside: valid memory, masked below
 #pragma unroll
-                            for (int k = 0; k < kChunk; ++k) v[tt][k] = src[k * plane];
+                            for (int k = 0; k < kChunk; ++k) v[tt][k] = (f1c + k * plane)[off];  // scalar plane base + 32-bit lane offset
                         }
                     }
 #pragma unroll
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
     while (true) {
         if (threadIdx.x == 0) next_item = atomicAdd(p.todo + 1, 1);
         __syncthreads();
-        const int it = next_item;
+        const int it = __builtin_amdgcn_readfirstlane(next_item);  // scalar: everything derived from it (b, map bases) stays in SGPRs
         if (it >= n) break;
         const unsigned wid = (unsigned)p.todo[2 + it / SUBS];
         const int sub = it % SUBS;
