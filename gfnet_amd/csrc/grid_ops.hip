@@ -75,6 +75,35 @@ __device__ __forceinline__ BilinC bilin_clamped(float gx, float gy, int W, int H
     return c;
 }
 
+// Pair form of a bilinear set-up: the two corners of an image row are adjacent, so one 8-byte gather (4-byte aligned)
+// fetches both.  o[0]/o[1] = offsets of the pair in rows y0 / y0+1, always inside the map (column clamped to 0..W-2, an
+// out-of-image row reads row 0); w = weights of (row y0: left, right; row y0+1: left, right) *of the fetched pixels*:
+// zero for a fetched pixel that is not the corner it stands in for, so out-of-image corners add an exact 0 and the
+// corner order nw, ne, sw, se of grid_sample is kept.
+struct BilinP {
+    unsigned o[2];
+    float w[4];
+};
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ BilinP bilin_pairs(float gx, float gy, int W, int H) {
+    const Bilin s = bilin_setup(gx, gy, W, H);
+    BilinP c;
+    const int ox = min(max(s.x0, 0), W - 2);
+    // fetched left pixel = column ox, right = ox + 1; corner columns are x0 (weights w*0) and x0+1 (weights w*1)
+    const float l0 = (s.xa & (s.x0 == ox)) ? 1.f : 0.f, l1 = (s.xb & (s.x0 + 1 == ox)) ? 1.f : 0.f;      // left stands for x0 / x0+1
+    const float r0 = (s.xa & (s.x0 == ox + 1)) ? 1.f : 0.f, r1 = (s.xb & (s.x0 + 1 == ox + 1)) ? 1.f : 0.f;  // right stands for x0 / x0+1
+    const float ta = s.ya ? 1.f : 0.f, tb = s.yb ? 1.f : 0.f;
+    c.o[0] = (unsigned)((s.ya ? s.y0 : 0) * W + ox);
+    c.o[1] = (unsigned)((s.yb ? s.y0 + 1 : 0) * W + ox);
+    // exactly one of (l0, l1) and one of (r0, r1) can be 1, so each product below is w or 0 -- no rounding added
+    c.w[0] = ta * (l0 * s.w00 + l1 * s.w01);
+    c.w[1] = ta * (r0 * s.w00 + r1 * s.w01);
+    c.w[2] = tb * (l0 * s.w10 + l1 * s.w11);
+    c.w[3] = tb * (r0 * s.w10 + r1 * s.w11);
+    return c;
+}
+
 // One thread per (direction, grid cell): both bilinear set-ups once, then the channels in groups of
 // 8 with all 64 gathers of a group in flight; stores run along the grid row for every channel.
 // A workgroup never straddles two directions (blockIdx.y = direction), so every plane base is a scalar and a load is
@@ -90,7 +119,9 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
                                                             float disp_scale) {
     const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
     const unsigned plane = (unsigned)(Hs * Ws), GG = (unsigned)(G * G);
-    const int b = blockIdx.y;
+    // symmetric batches: the two directions of one pair read the same two maps (query <-> support), so they are
+    // dispatched back to back and the second reader finds the maps in the memory-side cache
+    const int b = Bh < B ? ((blockIdx.y & 1) ? (int)(blockIdx.y >> 1) + Bh : (int)(blockIdx.y >> 1)) : (int)blockIdx.y;
     const unsigned cell = blockIdx.x * 256u + threadIdx.x;
     if (cell >= GG) return;
     const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
@@ -99,35 +130,49 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
     const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
     const float *fl = flow + (size_t)b * 2 * GG;
     const float fx = fl[cell], fy = fl[GG + cell];
-    const BilinC sa = bilin_clamped(cx, cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
-    const BilinC sb = bilin_clamped(fx, fy, Ws, Hs);  // x_hat = grid_sample(y, flow)                 network.py:537
-    unsigned oa[4], ob[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) oa[e] = (unsigned)sa.o[e], ob[e] = (unsigned)sb.o[e];
     float *o = d + (size_t)b * d_bs;
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        float va[8][4], vb[8][4];
+    if (Ws >= 2) {
+        const BilinP sa = bilin_pairs(cx, cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
+        const BilinP sb = bilin_pairs(fx, fy, Ws, Hs);  // x_hat = grid_sample(y, flow)                 network.py:537
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            f32x2u va[8][2], vb[8][2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
+            for (int k = 0; k < 8; ++k) {
+                const float *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                va[k][e] = qp[oa[e]];
-                vb[k][e] = sp[ob[e]];
+                for (int e = 0; e < 2; ++e) {
+                    va[k][e] = *reinterpret_cast<const f32x2u *>(qp + sa.o[e]);
+                    vb[k][e] = *reinterpret_cast<const f32x2u *>(sp + sb.o[e]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (c0 + k < C) {
+                    float ra = 0.f, rb = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        ra += va[k][e].x * sa.w[2 * e];
+                        ra += va[k][e].y * sa.w[2 * e + 1];
+                        rb += vb[k][e].x * sb.w[2 * e];
+                        rb += vb[k][e].y * sb.w[2 * e + 1];
+                    }
+                    (o + (size_t)(c0 + k) * GG)[cell] = ra;
+                    (o + (size_t)(C + c0 + k) * GG)[cell] = rb;
+                }
             }
         }
+    } else {  // one-column maps: no pair to fetch
+        const BilinC sa = bilin_clamped(cx, cy, Ws, Hs);
+        const BilinC sb = bilin_clamped(fx, fy, Ws, Hs);
+        for (int c = 0; c < C; ++c) {
+            float ra = 0.f, rb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (c0 + k < C) {
-                float ra = 0.f, rb = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ra += va[k][e] * sa.w[e];
-                    rb += vb[k][e] * sb.w[e];
-                }
-                (o + (size_t)(c0 + k) * GG)[cell] = ra;
-                (o + (size_t)(C + c0 + k) * GG)[cell] = rb;
+            for (int e = 0; e < 4; ++e) {
+                ra += (q + (size_t)c * plane)[sa.o[e]] * sa.w[e];
+                rb += (sm + (size_t)c * plane)[sb.o[e]] * sb.w[e];
             }
+            (o + (size_t)c * GG)[cell] = ra;
+            (o + (size_t)(C + c) * GG)[cell] = rb;
         }
     }
     // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549

@@ -44,6 +44,6 @@ for (c, hs, G, dd, r) in [(64, 32, 32, 64, 7), (32, 112, 64, 32, 4), (16, 224, 1
     flow = (torch.stack((gx, gy))[None] * 0.9).repeat(64, 1, 1, 1).contiguous()
     wgt = torch.randn(dd, 2, 1, 1, device="cuda")
     bias = torch.randn(dd, device="cuda")
-    t = timeit(lambda: ops.refiner_input(G, a, b, flow, wgt, bias, r, corr_in_other=False))
+    t = timeit(lambda: ops.refiner_input(G, a[:32], b[:32], flow, wgt, bias, r, corr_in_other=False))
     by = 4 * 64 * ((2 * c + dd) * G * G + 2 * c * hs * hs)
     print(f"refiner_input (no corr) c{c} hs{hs} G{G}: {t*1e3:.1f} us  ({by/t/1e6:.0f} GB/s of in+out bytes)")
