@@ -192,8 +192,10 @@ __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const fl
 
 // ys: pre-scaled point pairs (Bt, Mp/2, 4, 2) as written by kde4_prescale_kernel; box: (Bt, nblk, 8) =
 // min[4], max[4] of each block of 64 reference points (32 pairs).  One wave per block.
-__global__ __launch_bounds__(256) void kde4_bbox_kernel(const float *__restrict__ ys, float *__restrict__ box, int M, int Mp,
-                                                        int Bt) {
+// box32 (optional): (Bt, 2*nblk, 8) the same for the two 32-point halves of every block (the matrix-core kernel culls per
+// 32 x 32 tile).
+__global__ __launch_bounds__(256) void kde4_bbox_kernel(const float *__restrict__ ys, float *__restrict__ box, float *__restrict__ box32,
+                                                        int M, int Mp, int Bt) {
     const int lane = threadIdx.x & 63;
     const int nblk = (Mp + 63) >> 6;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -208,12 +210,23 @@ __global__ __launch_bounds__(256) void kde4_bbox_kernel(const float *__restrict_
         hi[d] = (m < M) ? v : -3e38f;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
             hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
         }
+    }
+    if (box32) {
+        const int l = lane & 31;
+        float *b32 = box32 + (wid * 2 + (lane >> 5)) * 8;
+        if (l < 4) b32[l] = lo[l];
+        else if (l < 8) b32[l] = hi[l - 4];
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        lo[d] = fminf(lo[d], __shfl_xor(lo[d], 32));
+        hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], 32));
     }
     if (lane < 4) box[wid * 8 + lane] = lo[lane];
     else if (lane < 8) box[wid * 8 + lane] = hi[lane - 4];
@@ -353,9 +366,19 @@ __global__ __launch_bounds__(256) void kde4_operands_kernel(const float *__restr
 //   * this file is compiled with -amdgpu-mfma-vgpr-form: the products land in VGPRs, not in AGPRs that cost one
 //     v_accvgpr_read per exponential (build.py).
 // What bounds the kernel is v_exp_f32 (quarter rate: 16 cycles per wave instruction) on the surviving pairs.
+//
+// SYM (queries == points, the call GFNet.sample makes): exp(-|x_i - x_j|^2) is symmetric, so a wave only visits the
+// blocks p >= its own block q.  A tile with p > q feeds the row sums of its 64 queries as before AND, summed down the
+// lane's column, the densities of the 64 points of block p -- half the exponentials.  The column sums of all waves meet
+// in one accumulator per point; to keep the result independent of the order in which waves arrive they are added as
+// 2^-40 fixed-point integers (integer addition is associative; densities < 2^23 fit 64 bits), and kde_combine_kernel
+// adds the two halves.  The diagonal block p == q holds both (i,j) and (j,i) and feeds row sums only.
+constexpr float kKdeFixScale = 1099511627776.f;  // 2^40
+template <bool SYM>
 __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__restrict__ xs, const bf16x8 *__restrict__ aop,
                                                                 const bf16x8 *__restrict__ bop, const float *__restrict__ box,
-                                                                float *__restrict__ part, int N, int Mp, int NT, int MT) {
+                                                                float *__restrict__ part, unsigned long long *__restrict__ colacc,
+                                                                int N, int Mp, int NT, int MT, int tile_cull) {
     const int bt = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = blockIdx.x * kKdeThreads + wave * 64;
@@ -364,7 +387,8 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__r
     const int MS = gridDim.y, ms = blockIdx.y;
     const int nblk = (Mp + 63) >> 6;
     const int per = (nblk + MS - 1) / MS;
-    const int b0 = ms * per, b1 = min(nblk, b0 + per);
+    const int qblk = q0 >> 6;
+    const int b0 = SYM ? max(ms * per, qblk) : ms * per, b1 = min(nblk, ms * per + per);
     const float4 xv = (n < N) ? reinterpret_cast<const float4 *>(xs)[(size_t)bt * N + n] : make_float4(0, 0, 0, 0);
     float qlo[4] = {xv.x, xv.y, xv.z, xv.w}, qhi[4] = {xv.x, xv.y, xv.z, xv.w};
     if (n >= N) {
@@ -372,35 +396,53 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__r
         for (int d = 0; d < 4; ++d) { qlo[d] = 3e38f; qhi[d] = -3e38f; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {  // lanes 0-31 / 32-63: the two row tiles
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             qlo[d] = fminf(qlo[d], __shfl_xor(qlo[d], o));
             qhi[d] = fmaxf(qhi[d], __shfl_xor(qhi[d], o));
         }
     }
+    float ql0[4], qh0[4], ql1[4], qh1[4];  // wave-uniform boxes of row tile 0 / 1 (scalar registers)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        ql0[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qlo[d]), 0));
+        qh0[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qhi[d]), 0));
+        ql1[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qlo[d]), 32));
+        qh1[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qhi[d]), 32));
+    }
     const int col = lane & 31, kh = lane >> 5;
+    unsigned long long *cacc = SYM ? colacc + (size_t)bt * N : nullptr;
     const bf16x8 *ap = aop + ((size_t)bt * NT + (q0 >> 5)) * 128 + kh * 32 + col;
     const bf16x8 a00 = ap[0], a01 = ap[64], a10 = ap[128], a11 = ap[192];  // [row tile][MFMA]
     const bf16x8 *bp = bop + (size_t)bt * MT * 128 + kh * 32 + col;
-    const float4 *bx = reinterpret_cast<const float4 *>(box + (size_t)bt * nblk * 8);
+    const float4 *bx = reinterpret_cast<const float4 *>(box + (size_t)bt * nblk * 16);  // 32-point tile boxes: [tile][lo4, hi4]
     f32x2 acc0[8], acc1[8];  // [r/2] = rows r, r+1 of the lane's column (packed adds)
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc0[r] = f32x2{0.f, 0.f}, acc1[r] = f32x2{0.f, 0.f};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto near = [&](const float (&ql)[4], const float (&qh)[4], const float4 lo, const float4 hi) {
+        const float g0 = fmaxf(fmaxf(ql[0] - hi.x, lo.x - qh[0]), 0.f), g1 = fmaxf(fmaxf(ql[1] - hi.y, lo.y - qh[1]), 0.f);
+        const float g2 = fmaxf(fmaxf(ql[2] - hi.z, lo.z - qh[2]), 0.f), g3 = fmaxf(fmaxf(ql[3] - hi.w, lo.w - qh[3]), 0.f);
+        return !(fmaf(g3, g3, fmaf(g2, g2, fmaf(g1, g1, g0 * g0))) > kKdeCutoffLog2);
+    };
     for (int base = b0; base < b1; base += 64) {
-        bool keep = false;
+        // lane L tests the four 32 x 32 tiles of (this wave's two row tiles) x (block base+L's two column tiles)
+        bool k00 = false, k01 = false, k10 = false, k11 = false;  // [row tile][column tile]
         if (base + lane < b1) {
-            const float4 lo = bx[(base + lane) * 2], hi = bx[(base + lane) * 2 + 1];
-            const float g0 = fmaxf(fmaxf(qlo[0] - hi.x, lo.x - qhi[0]), 0.f), g1 = fmaxf(fmaxf(qlo[1] - hi.y, lo.y - qhi[1]), 0.f);
-            const float g2 = fmaxf(fmaxf(qlo[2] - hi.z, lo.z - qhi[2]), 0.f), g3 = fmaxf(fmaxf(qlo[3] - hi.w, lo.w - qhi[3]), 0.f);
-            keep = !(fmaf(g3, g3, fmaf(g2, g2, fmaf(g1, g1, g0 * g0))) > kKdeCutoffLog2);
+            const float4 *t = bx + (size_t)(base + lane) * 4;
+            const float4 lo0 = t[0], hi0 = t[1], lo1 = t[2], hi1 = t[3];
+            k00 = near(ql0, qh0, lo0, hi0); k01 = near(ql0, qh0, lo1, hi1);
+            k10 = near(ql1, qh1, lo0, hi0); k11 = near(ql1, qh1, lo1, hi1);
+            if (!tile_cull) k00 = k01 = k10 = k11 = (k00 | k01 | k10 | k11);  // experiments: cull per 64 x 64 block only
         }
-        unsigned long long mask = __ballot(keep);
+        const unsigned long long m00 = __ballot(k00), m01 = __ballot(k01), m10 = __ballot(k10), m11 = __ballot(k11);
+        unsigned long long mask = m00 | m01 | m10 | m11;
         if (!mask) continue;
         bf16x8 c0, c1, c2, c3;  // [column tile][MFMA] of the current block
+        int cur = base + __builtin_ctzll(mask), nxt = 0;
         {
-            const bf16x8 *b = bp + (size_t)(base + __builtin_ctzll(mask)) * 256;
+            const bf16x8 *b = bp + (size_t)cur * 256;
             mask &= mask - 1;
             c0 = b[0], c1 = b[64], c2 = b[128], c3 = b[192];
         }
@@ -410,30 +452,75 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__r
             const bool more = mask != 0;
             bf16x8 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
             if (more) {
-                const bf16x8 *b = bp + (size_t)(base + __builtin_ctzll(mask)) * 256;
+                nxt = base + __builtin_ctzll(mask);
+                const bf16x8 *b = bp + (size_t)nxt * 256;
                 mask &= mask - 1;
                 n0 = b[0], n1 = b[64], n2 = b[128], n3 = b[192];
             }
-            f32x16 e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c0, zero16, 0, 0, 0);
-            f32x16 e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c0, zero16, 0, 0, 0);
-            e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c1, e0, 0, 0, 0);
-            e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c1, e1, 0, 0, 0);
-            f32x16 f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c2, zero16, 0, 0, 0);
-            f32x16 f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c2, zero16, 0, 0, 0);
-            f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c3, f0, 0, 0, 0);
-            f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c3, f1, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                acc0[r] += f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
-                acc1[r] += f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
+            const int bit = cur - base;
+            const bool s00 = (m00 >> bit) & 1, s01 = (m01 >> bit) & 1, s10 = (m10 >> bit) & 1, s11 = (m11 >> bit) & 1;  // scalar
+            f32x16 e0 = zero16, e1 = zero16, f0 = zero16, f1 = zero16;
+            if (s00) {
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c0, zero16, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c1, e0, 0, 0, 0);
             }
+            if (s10) {
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c0, zero16, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c1, e1, 0, 0, 0);
+            }
+            if (s01) {
+                f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c2, zero16, 0, 0, 0);
+                f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c3, f0, 0, 0, 0);
+            }
+            if (s11) {
+                f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c2, zero16, 0, 0, 0);
+                f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c3, f1, 0, 0, 0);
+            }
+            f32x2 cs0 = f32x2{0.f, 0.f}, cs1 = f32x2{0.f, 0.f};  // SYM: this lane's column of the two column tiles
+            if (s00) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                acc0[r] += f32x2{__builtin_amdgcn_exp2f(-f0[2 * r]), __builtin_amdgcn_exp2f(-f0[2 * r + 1])};
-                acc1[r] += f32x2{__builtin_amdgcn_exp2f(-f1[2 * r]), __builtin_amdgcn_exp2f(-f1[2 * r + 1])};
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
+                    acc0[r] += x;
+                    if (SYM) cs0 += x;
+                }
+            }
+            if (s10) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
+                    acc1[r] += x;
+                    if (SYM) cs0 += x;
+                }
+            }
+            if (s01) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-f0[2 * r]), __builtin_amdgcn_exp2f(-f0[2 * r + 1])};
+                    acc0[r] += x;
+                    if (SYM) cs1 += x;
+                }
+            }
+            if (s11) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-f1[2 * r]), __builtin_amdgcn_exp2f(-f1[2 * r + 1])};
+                    acc1[r] += x;
+                    if (SYM) cs1 += x;
+                }
+            }
+            if (SYM && cur != qblk) {  // wave-uniform
+                // rows 4kh.. of both row tiles are in this lane, the other half of the rows in lane ^ 32
+                float s0 = cs0.x + cs0.y, s1 = cs1.x + cs1.y;
+                s0 += __shfl_xor(s0, 32);
+                s1 += __shfl_xor(s1, 32);
+                const float sv = kh ? s1 : s0;  // lanes 0-31: column tile 0, lanes 32-63: column tile 1
+                const int pt = cur * 64 + lane;
+                if (pt < N) atomicAdd(cacc + pt, (unsigned long long)(sv * kKdeFixScale));
             }
             if (!more) break;
             c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+            cur = nxt;
         }
     }
     // sum the 32 columns (lanes with the same kh), then lanes col == 0 hold rows (r&3) + 8(r>>2) + 4kh of each row tile
@@ -485,6 +572,17 @@ __global__ __launch_bounds__(256) void kde_reduce_kernel(const float *__restrict
     float s = 0.f;
     for (int k = 0; k < MS; ++k) s += part[((size_t)bt * MS + k) * N + n];  // fixed order: reproducible
     out[idx] = s;
+}
+
+// symmetric kernel: density = row sums (split-M partials, fixed order) + column sums (fixed point)
+__global__ __launch_bounds__(256) void kde_combine_kernel(const float *__restrict__ part, const unsigned long long *__restrict__ colacc,
+                                                          float *__restrict__ out, int N, int MS, int Bt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Bt * N) return;
+    const int bt = (int)(idx / N), n = (int)(idx - (long)bt * N);
+    float s = 0.f;
+    for (int k = 0; k < MS; ++k) s += part[((size_t)bt * MS + k) * N + n];
+    out[idx] = s + (float)((double)colacc[idx] * (1.0 / 1099511627776.0));
 }
 
 // GFNet.sample's elementwise steps (model/network.py:391-393, 409-410)
@@ -542,8 +640,9 @@ GFN_EXPORT int gfn_kde_morton_sort(const float *x, float *x_sorted, int *perm, i
 GFN_EXPORT int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M) {
     const int Mp = (M + 1) & ~1;
     const int64_t nblk = (Mp + 63) / 64, ntile = (N + 63) / 64 * 2;
-    return (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4 + Bt * nblk * 8 + (int64_t)Bt * 32 * N + 64 +
-           (Bt * ntile * 32 + Bt * nblk * 64) * 16 + 8;  // + the matrix-core operand images (64 B per query / point)
+    return (int64_t)Bt * N * 4 + (int64_t)Bt * Mp * 4 + Bt * nblk * 24 + (int64_t)Bt * 32 * N + 64 +
+           (Bt * ntile * 32 + Bt * nblk * 64) * 16 + 8 +  // + the matrix-core operand images (64 B per query / point)
+           (int64_t)Bt * N * 2 + 4;                        // + the fixed-point column sums of the symmetric kernel
 }
 
 // Density of spatially sorted 4-D points (see kde4_culled_kernel): x (Bt,N,4), y (Bt,M,4), both in
@@ -559,11 +658,12 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
     const float scale = (float)sqrt(1.4426950408889634 / (2.0 * std * std));
     const int Mp = (M + 1) & ~1, nblk = (Mp + 63) / 64;
     float *xs = scratch, *ys = xs + (int64_t)Bt * N * 4, *box = ys + (int64_t)Bt * Mp * 4;
-    float *part = box + (((int64_t)Bt * nblk * 8 + 3) & ~3);
+    float *box32 = box + (((int64_t)Bt * nblk * 8 + 3) & ~3);  // per 32-point tile
+    float *part = box32 + (int64_t)Bt * nblk * 16;
     const long tot = (long)Bt * 4 * (N > Mp ? N : Mp);
     hipLaunchKernelGGL(kde4_prescale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, y, xs, ys, N, M, 4L,
                        (long)M * 4, scale, Bt);
-    hipLaunchKernelGGL(kde4_bbox_kernel, dim3((unsigned)(((long)Bt * nblk + 3) / 4)), dim3(256), 0, s, ys, box, M, Mp, Bt);
+    hipLaunchKernelGGL(kde4_bbox_kernel, dim3((unsigned)(((long)Bt * nblk + 3) / 4)), dim3(256), 0, s, ys, box, box32, M, Mp, Bt);
     int MS = 1;
     {   // same rule as the dense kernel: enough workgroups for the chip, at least 8 blocks of points per split
         const long blocks = (long)Bt * ((N + kKdeThreads - 1) / kKdeThreads);
@@ -571,6 +671,9 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
     }
     float *dst = MS > 1 ? part : out;
     static const bool valu_only = getenv("GFN_KDE_VALU") != nullptr;  // experiments: the difference-form kernel
+    static const bool no_sym = getenv("GFN_KDE_NOSYM") != nullptr;    // experiments: full N x N evaluation
+    const bool sym = x == y && N == M && !no_sym;
+    static const int tile_cull = getenv("GFN_KDE_NOTILE") == nullptr;  // experiments: 0 = cull per block only
     if (valu_only) {
         hipLaunchKernelGGL(kde4_culled_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, ys,
                            box, dst, N, Mp);
@@ -582,8 +685,19 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
         const long npts = (long)Bt * 32 * (NT > MT ? NT : MT);
         hipLaunchKernelGGL(kde4_operands_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, s, xs, ys, aop, bop, N, M, Mp, NT,
                            MT, Bt);
-        hipLaunchKernelGGL(kde4_mfma_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, aop, bop,
-                           box, dst, N, Mp, NT, MT);
+        if (sym) {
+            unsigned long long *colacc = reinterpret_cast<unsigned long long *>(bop + (int64_t)Bt * MT * 128);
+            if (hipMemsetAsync(colacc, 0, sizeof(unsigned long long) * (size_t)Bt * N, s) != hipSuccess)
+                return gfn::fail(GFN_ERR_LAUNCH, "kde_sorted: memset failed");
+            hipLaunchKernelGGL(kde4_mfma_kernel<true>, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, aop,
+                               bop, box32, part, colacc, N, Mp, NT, MT, tile_cull);
+            if (int e = gfn::check_launch("kde4_mfma_kernel")) return e;
+            const long total = (long)Bt * N;
+            hipLaunchKernelGGL(kde_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, colacc, out, N, MS, Bt);
+            return gfn::check_launch("kde_combine_kernel");
+        }
+        hipLaunchKernelGGL(kde4_mfma_kernel<false>, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, aop, bop,
+                           box32, dst, nullptr, N, Mp, NT, MT, tile_cull);
         if (int e = gfn::check_launch("kde4_mfma_kernel")) return e;
     }
     if (MS > 1) {

@@ -46,3 +46,18 @@ idx = torch.randperm(N, device=x.device)[:4096]
 sub = xs[0, idx]
 dd = torch.cdist(sub, sub) ** 2 * scale2
 print(f"point pairs within 2^-32: {float((dd <= 32).float().mean()):.3f} (random 4096 points of row 0)")
+
+
+def timeit(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print(f"kde_density on the captured input: {timeit(lambda: orig(x, std=0.1)):.1f} us (sort + operands + kernel + scatter)")
