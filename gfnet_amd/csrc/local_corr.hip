@@ -100,6 +100,18 @@ __device__ __forceinline__ void lane_group(int lane, int &g, int &s) {
     g = ((lane >> 5) << 1) | (even ? 0 : 1);
 }
 
+// min over the 64 lanes of a wave, returned to every lane (scalar): four row shifts inside each row of 16, then the two
+// row broadcasts of the GFX9 DPP set; lanes without a source keep their own value (min is idempotent).
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Normalised -> pixel coordinate exactly as grid_sample(align_corners=False) un-normalises.
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * (float)size - 1.f) / 2.f; }
 
@@ -351,7 +363,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     const int G = p.G, H = p.H, W = p.W;
 #ifdef GFN_ABLATE
     const bool stamping = ABL(p, 512) && blockIdx.x == 2000 && tid == 0 && !SECOND;
-    long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
     auto cell_gi = [&](int cell) { return row0 + cell / TW; };
@@ -363,6 +375,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     if (tid == 0) { *nSlow = 0; *allInside = 1; }
     __syncthreads();
     const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;  // +-2r/W, +-2r/H as fp32
+    // the cell's flow: requested before the f0 block below so that the two DRAM round trips of the set-up overlap
+    float pre_nx = 0.f, pre_ny = 0.f;
+    if (tid < NC && cell_ok(tid)) cell_coords(p, b, cell_gi(tid), cell_gj(tid), pre_nx, pre_ny);
     // the tile's f0 block (NC cells x C channels, 8-16 KB): coalesced 64-byte row segments -> LDS,
     // cell-major.  (Loading f0 per lane would issue 16 loads per round and chunk that fetch 16 bytes each.)
     {
@@ -388,6 +403,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             }
         }
     }
+    STAMP(11);
     int bx0 = kFar, by0 = kFar, bx1 = -kFar, by1 = -kFar;  // this cell's window clipped to the image
     bool inside = true;                                      // ... and whether clipping changed nothing
     if (tid < NC) {
@@ -395,7 +411,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         int X0 = kFar, Y0 = kFar, slow = 0;
         float nx = 0.f, ny = 0.f;
         if (cell_ok(tid)) {
-            cell_coords(p, b, gi, gj, nx, ny);
+            nx = pre_nx; ny = pre_ny;
             // patch origin = floor of the reference's own fp32 coordinate of tap 0:
             // taps kx=0..2R then read columns kx and kx+1 of the patch
             const float fx = floorf(unnorm(nx + gfn::linspace_at(xlo, xhi, D, 0), W));
@@ -420,20 +436,23 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         cellNy[tid] = ny;
         cellSlow[tid] = slow;
     }
+    STAMP(12);
     if (STAGED && wave < (NC + 63) / 64) {  // bounding box: reduce inside the wave (all 64 lanes take
-        // part, idle ones with the identity), then one LDS atomic per wave and bound
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
-            bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
-        }
+        // part, idle ones with the identity) with DPP row shifts / broadcasts -- the ds_bpermute butterfly took 1500+ cycles
+        // of every tile's critical path -- then one LDS update per wave and bound
+        bx0 = wave_min_i32(bx0); by0 = wave_min_i32(by0);
+        bx1 = -wave_min_i32(-bx1); by1 = -wave_min_i32(-by1);
         // cells off the grid or with absurd flow have inside == true but an empty box: harmless
         const bool all_in = __all(inside || tid >= NC);
         if (lane == 0) {
-            atomicMin(bbox + 0, bx0);
-            atomicMin(bbox + 1, by0);
-            atomicMax(bbox + 2, bx1);
-            atomicMax(bbox + 3, by1);
+            if (NC <= 64) {  // a single wave holds every cell: plain stores
+                bbox[0] = bx0; bbox[1] = by0; bbox[2] = bx1; bbox[3] = by1;
+            } else {
+                atomicMin(bbox + 0, bx0);
+                atomicMin(bbox + 1, by0);
+                atomicMax(bbox + 2, bx1);
+                atomicMax(bbox + 3, by1);
+            }
             if (!all_in) *allInside = 0;
         }
     }
@@ -677,9 +696,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     STAMP(10);
 #ifdef GFN_ABLATE
     if (stamping)
-        printf("stamps(cycles from entry): setup-done %lld | barrier %lld | addressing %lld | chunk0 staged %lld | D chunk0 %lld | chunk1 staged %lld | "
+        printf("stamps(cycles from entry): flow-issued+f0 staged %lld | cells done %lld | setup-done %lld | barrier %lld | addressing %lld | chunk0 staged %lld | D chunk0 %lld | chunk1 staged %lld | "
                "D chunk1 %lld | barrier %lld | dbuf+table %lld | combine+stores issued %lld\n",
-               stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0],
+               stamp[11] - stamp[0], stamp[12] - stamp[0], stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0],
                stamp[7] - stamp[0], stamp[8] - stamp[0], stamp[9] - stamp[0], stamp[10] - stamp[0]);
 #endif
     // ---- flagged cells: general per-tap routine (about one cell in 10^4) ------------------------

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 import synth  # noqa: E402
 from gfnet_amd.utils.local_correlation import local_correlation  # noqa: E402
 
-B, c, hs, G, r = 64, 32, 112, 64, 4
+B, c, hs, G, r = (64, 32, 112, 64, 4) if len(sys.argv) < 2 else tuple(int(v) for v in sys.argv[1:6])
 f0 = torch.randn(B, c, G, G, device="cuda")
 f1 = torch.randn(B, c, hs, hs, device="cuda")
 flow = torch.from_numpy(np.tile(synth.homography_flow(2, G, 5), (B // 2, 1, 1, 1))).cuda()
