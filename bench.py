@@ -290,7 +290,7 @@ def main():
                    "stages": "corr_softargmax, refiner_input+local_corr x(4+3 scales), flow_update, resize, match_post, "
                              "sample(2 draws without replacement + KDE 20000^2), RANSAC(2000)+DLT+LM, H all-gather",
                    "excluded": ("DINOv2/FPN backbone and refiner conv stacks (PyTorch-ROCm host code); stand-in increment = "
-                                "exact residual to the true warp (2 torch elementwise ops per refiner call)") if args.conv_stack == "off"
+                                "exact residual to the true warp (1 torch elementwise op per refiner call)") if args.conv_stack == "off"
                    else "DINOv2/FPN backbone (PyTorch-ROCm host code)",
                    "refiner_conv_stack": "off" if args.conv_stack == "off" else
                    f"reference architecture (9 dw5x5+BN+ReLU+1x1 blocks + out conv per refiner call, C=417/361/177/73/24), random-init, "
