@@ -119,8 +119,8 @@ _scratch = {}
 
 
 def scratch(device, nbytes):
-    """A per-device, grow-only int32 scratch buffer (stream-ordered reuse: one host thread per stream)."""
-    key = (device.type, device.index)
+    """A per-(device, stream), grow-only int32 scratch buffer (stream-ordered reuse: one host thread per stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
