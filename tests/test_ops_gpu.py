@@ -325,6 +325,27 @@ def test_kde_culled_equals_dense_and_oracle_on_match_like_points():
     np.testing.assert_allclose(c2[0], oracle.kde(x[0], 0.1, half=False, down=8), rtol=1e-4)
 
 
+@pytest.mark.parametrize("Bt,N", [(1, 4097), (5, 9000), (32, 6000)])
+def test_kde_symmetric_path_is_deterministic_and_matches_oracle(Bt, N):
+    """queries == points takes the symmetric kernel (upper-triangle blocks; column sums meet in fixed-point
+    integer accumulators): bit-identical from run to run whatever order the waves arrive in, ragged last block,
+    with and without the split over column blocks (small / large batches)."""
+    from gfnet_amd import ops
+
+    rng = np.random.default_rng(Bt * 1000 + N)
+    a = rng.uniform(-1, 1, size=(Bt, N, 2))
+    x = np.concatenate((a, 0.9 * a + 0.02 * rng.standard_normal(a.shape)), -1).astype(np.float32)
+    xd = dev(x)
+    first = host(ops.kde_density(xd, std=0.1, cull=True))
+    for _ in range(3):
+        assert np.array_equal(first, host(ops.kde_density(xd, std=0.1, cull=True)))
+    for bt in (0, Bt - 1):
+        np.testing.assert_allclose(first[bt], oracle.kde(x[bt], 0.1, half=False), rtol=1e-4)
+    # same points handed in as a separate reference set: the full N x M kernel, same densities
+    other = host(ops.kde_density(xd, xd.clone(), std=0.1, cull=True))
+    np.testing.assert_allclose(other, first, rtol=2e-5)
+
+
 # ---- N3 image resize + normalise ----------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["down", "up", "same", "mixed"])
 def test_g9_resize_normalise_hip(case):
