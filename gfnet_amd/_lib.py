@@ -26,6 +26,7 @@ _SIGNATURES = {
     "gfn_refiner_input_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_vp],
     "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
     "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
+    "gfn_interp_bilinear_pair_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "gfn_flow_update_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_flow_update_out_fwd": [c_vp] * 5 + [c_i64, c_vp, c_i64, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_match_post_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_int] * 4 + [c_vp],
@@ -123,7 +124,8 @@ def scratch(device, nbytes):
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
+        # zero-filled: gfn_local_corr_fwd wants its counters zero on entry and leaves them zero (include/gfnet_hip.h)
+        buf = torch.zeros((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
         _scratch[key] = buf
     return buf
 

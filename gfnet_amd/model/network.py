@@ -229,8 +229,7 @@ class GFNet(nn.Module):
                 if upsample:
                     if pre_corresps is None:
                         raise ValueError("upsampling refinement needs pre_corresps")
-                    flow = ops.interpolate_bilinear(pre_corresps["flow"], num_grid[0])          # :238-243
-                    certainty = ops.interpolate_bilinear(pre_corresps["certainty"], num_grid[0])  # :244-249
+                    flow, certainty = ops.interpolate_bilinear_pair(pre_corresps["flow"], pre_corresps["certainty"], num_grid[0])  # :238-249
                 else:
                     flow = ops.corr_softargmax(f0, f1, symmetric=symmetric)                      # :251-252
                     certainty = torch.zeros((flow.shape[0], 1) + tuple(flow.shape[2:]), device=flow.device)  # :253
@@ -243,8 +242,7 @@ class GFNet(nn.Module):
                                                   zero_small=not self.training, first_iteration=(itr == 0))  # :262-268
                 corresps[scale][itr + 1] = {"flow": flow, "certainty": certainty}
             if scale != "1":                                                                      # :271-281
-                flow = ops.interpolate_bilinear(flow, num_grid[idx + 1])
-                certainty = ops.interpolate_bilinear(certainty, num_grid[idx + 1])
+                flow, certainty = ops.interpolate_bilinear_pair(flow, certainty, num_grid[idx + 1])
         return corresps
 
     def forward(self, batch, symmetric=False, upsample=False, scale_factor=1, pre_corresps=None, visualization=False):

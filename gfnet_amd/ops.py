@@ -130,6 +130,23 @@ def interpolate_bilinear(x, size):
     return out
 
 
+def interpolate_bilinear_pair(a, b, size):
+    """interpolate_bilinear of two tensors with the same batch and spatial size in one launch (flow + certainty,
+    model/network.py:238-249,271-281)."""
+    dev = require_gpu(a, b)
+    a, b = f32c(a), f32c(b)
+    B, Ca, H, W = a.shape
+    if b.shape[0] != B or tuple(b.shape[2:]) != (H, W):
+        raise ValueError(f"interpolate_bilinear_pair: {tuple(a.shape)} vs {tuple(b.shape)}")
+    Cb = b.shape[1]
+    Ho, Wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    oa = torch.empty((B, Ca, Ho, Wo), device=dev, dtype=torch.float32)
+    ob = torch.empty((B, Cb, Ho, Wo), device=dev, dtype=torch.float32)
+    check(_L().gfn_interp_bilinear_pair_fwd(ptr(a), ptr(oa), B * Ca, ptr(b), ptr(ob), B * Cb, H, W, Ho, Wo, stream_ptr(dev)),
+          "gfn_interp_bilinear_pair_fwd")
+    return oa, ob
+
+
 def flow_update_(flow, certainty, delta, disp_prev, scale, W0, H0, zero_small=True, first_iteration=True):
     """In place: model/network.py:262-268.  delta is the refiner output (B,3,G,G) (channels 0,1 =
     displacement, 2 = certainty increment); disp_prev (B,2,G,G) carries the previous displacement."""

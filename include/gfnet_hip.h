@@ -65,7 +65,9 @@ int gfn_device_arch(char *buf, int buflen);
  * Fast path (LDS-tiled, shared bilinear fractions): C % 16 == 0, 1 <= r <= 7, !grid_based,
  * win_h == H, win_w == W, and `scratch` (device memory, gfn_local_corr_scratch_bytes(B, G) bytes,
  * 4-byte aligned; holds the list of tiles whose search windows do not fit the LDS stage and are
- * finished by a second, gather-based launch).  Anything else -- including scratch == NULL -- runs
+ * finished by a second, gather-based launch.  Its first 16 bytes are counters that must be ZERO on entry: zero
+ * them once after allocation -- every successful call leaves them zero again (the second launch resets them, so
+ * no memset precedes a call); after a call that returned an error, zero them again before reuse).  Anything else -- including scratch == NULL -- runs
  * the general per-tap kernel.  Flow values are unrestricted (out-of-image taps read zeros).
  */
 int64_t gfn_local_corr_scratch_bytes(int B, int G);
@@ -133,6 +135,10 @@ int gfn_grid_sample_fwd(const float *in, const float *grid, float *out, int64_t 
 /* F.interpolate(x, size=(Ho,Wo), mode='bilinear', align_corners=False) -- model/network.py:238-249,
  * 271-281, 333-335.  in (BC,H,W) -> out (BC,Ho,Wo). */
 int gfn_interp_bilinear_fwd(const float *in, float *out, int BC, int H, int W, int Ho, int Wo, gfn_stream_t stream);
+/* The same for two tensors of one spatial size in a single launch -- the flow (B,2,H,W) and certainty (B,1,H,W) pair the
+ * scale loop resizes together at model/network.py:238-249 and 271-281. */
+int gfn_interp_bilinear_pair_fwd(const float *in_a, float *out_a, int BCa, const float *in_b, float *out_b, int BCb, int H, int W,
+                                 int Ho, int Wo, gfn_stream_t stream);
 
 /* Flow/certainty accumulation of one refiner iteration -- model/network.py:262-268, in place:
  *   disp = scale * (delta[:,0]/(4*W0), delta[:,1]/(4*H0)); eval mode (zero_small): components with

@@ -136,6 +136,15 @@ def test_grid_sample_and_interpolate_vs_oracle():
     g5 = load_golden("g5_forward_loop")  # flow upsampling between scales on reference data
     f = g5["flow.2.1"]
     assert_close(host(ops.interpolate_bilinear(dev(f), 32)), oracle.interpolate_bilinear(f, 32), 1e-6, "flow up")
+    # flow + certainty in one launch: bit-identical to the two single calls
+    c = synth.lattice_normalish((f.shape[0], 1) + f.shape[2:], 93)
+    fa, ca = ops.interpolate_bilinear_pair(dev(f), dev(c), 32)
+    assert np.array_equal(host(fa), host(ops.interpolate_bilinear(dev(f), 32)))
+    assert np.array_equal(host(ca), host(ops.interpolate_bilinear(dev(c), 32)))
+    assert_close(host(ca), oracle.interpolate_bilinear(c, 32), 1e-6, "certainty up")
+    fb, cb = ops.interpolate_bilinear_pair(dev(x), dev(x[:, :2]), (9, 40))
+    assert_close(host(fb), oracle.interpolate_bilinear(x, (9, 40)), 1e-6, "pair a")
+    assert_close(host(cb), oracle.interpolate_bilinear(x[:, :2], (9, 40)), 1e-6, "pair b")
 
 
 # ---- A5 flow update, A6 match post ------------------------------------------------------------------

@@ -25,7 +25,7 @@ def wrapped(*a):
     import ctypes as ct
     hip = ct.CDLL("libamdhip64.so")
     buf = ct.c_int(0)
-    hip.hipMemcpy(ct.byref(buf), scratch, 4, 2)
+    hip.hipMemcpy(ct.byref(buf), ct.c_void_p(getattr(scratch, 'value', scratch) + 12), 4, 2)  # int 3: the last call's count
     rounds = 2 if r <= 4 else 1
     tiles = B * ((G + 15) // 16) * ((G + 2 * rounds - 1) // (2 * rounds))
     seen.append((C, H, G, r, buf.value, tiles))

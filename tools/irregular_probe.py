@@ -47,7 +47,7 @@ for G, x, y, fl, r, d, Dd in calls:
     CH = d.shape[1]
     out = d[:, 2 * C + Dd:]
     nscr = int(L.gfn_local_corr_scratch_bytes(B, G))
-    scr = torch.empty(nscr, dtype=torch.uint8, device="cuda")
+    scr = torch.zeros(nscr, dtype=torch.uint8, device="cuda")
     st = stream_ptr(x.device)
     print(f"c{C} hs{Hs} G{G} r{r}")
     for name, v in (("full", 0), ("no flagged-cell redo", 16), ("no gather variant", 1024), ("neither", 1040), ("gather loads at offset 0", 2048)):
