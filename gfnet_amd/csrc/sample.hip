@@ -62,14 +62,37 @@ __device__ unsigned radix_pass(const unsigned *__restrict__ keys, int N, unsigne
     for (int e = tid; e < BINS; e += kSelThreads) hist[e] = prefilled ? prefilled[e] : 0;
     __syncthreads();
     if (!prefilled) {
-        constexpr int UF = 8;  // independent loads in flight per thread (a row is 1.6 MB, L2 resident)
-        for (int n0 = tid; n0 < N; n0 += UF * kSelThreads) {
-            unsigned k[UF];
+        // a pass is a chain of L2 round trips for the single workgroup of a row: 16-byte loads, 4 in flight per thread
+        // (4 keys each) when the row allows, else 8 scalar loads
+        const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(keys) & 15) == 0);
+        if (vec) {
+            constexpr int UF = 4;
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+            const int N4 = N >> 2;
+            for (int n0 = tid; n0 < N4; n0 += UF * kSelThreads) {
+                uint4 k[UF];
 #pragma unroll
-            for (int q = 0; q < UF; ++q) k[q] = n0 + q * kSelThreads < N ? keys[n0 + q * kSelThreads] : ~prefix;
+                for (int q = 0; q < UF; ++q) k[q] = n0 + q * kSelThreads < N4 ? k4[n0 + q * kSelThreads] : make_uint4(~prefix, ~prefix, ~prefix, ~prefix);
 #pragma unroll
-            for (int q = 0; q < UF; ++q)
-                if (n0 + q * kSelThreads < N && (k[q] & prefix_mask) == prefix) atomicAdd(&hist[(k[q] >> shift) & (BINS - 1)], 1u);
+                for (int q = 0; q < UF; ++q) {
+                    if (n0 + q * kSelThreads < N4) {
+                        if ((k[q].x & prefix_mask) == prefix) atomicAdd(&hist[(k[q].x >> shift) & (BINS - 1)], 1u);
+                        if ((k[q].y & prefix_mask) == prefix) atomicAdd(&hist[(k[q].y >> shift) & (BINS - 1)], 1u);
+                        if ((k[q].z & prefix_mask) == prefix) atomicAdd(&hist[(k[q].z >> shift) & (BINS - 1)], 1u);
+                        if ((k[q].w & prefix_mask) == prefix) atomicAdd(&hist[(k[q].w >> shift) & (BINS - 1)], 1u);
+                    }
+                }
+            }
+        } else {
+            constexpr int UF = 8;
+            for (int n0 = tid; n0 < N; n0 += UF * kSelThreads) {
+                unsigned k[UF];
+#pragma unroll
+                for (int q = 0; q < UF; ++q) k[q] = n0 + q * kSelThreads < N ? keys[n0 + q * kSelThreads] : ~prefix;
+#pragma unroll
+                for (int q = 0; q < UF; ++q)
+                    if (n0 + q * kSelThreads < N && (k[q] & prefix_mask) == prefix) atomicAdd(&hist[(k[q] >> shift) & (BINS - 1)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -125,40 +148,106 @@ __global__ __launch_bounds__(kSelThreads) void race_select_kernel(const unsigned
     const unsigned T = p2 | d3;  // the K-th largest key; `need` of the elements equal to it are taken, in index order
     // ordered output without per-chunk barriers: every wave owns one contiguous 1/16 of the row, counts its winners,
     // the sixteen counts are scanned once, then the wave walks its range again and writes at its running offsets
-    const int per_wave = ((N + kSelWaves - 1) / kSelWaves + 63) & ~63;
+    const int per_wave = ((N + kSelWaves - 1) / kSelWaves + 255) & ~255;
     const int w0 = wave * per_wave, w1 = min(N, w0 + per_wave);
-    constexpr int UF = 4;
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(keys) & 15) == 0);  // w0, w1 are multiples of 4 then
+    const unsigned long long below = (1ull << lane) - 1ull;
     unsigned cnt_gt = 0, cnt_eq = 0;
-    for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
-        unsigned k[UF];
+    if (vec) {
+        // lane l holds elements 4l..4l+3 of a 256-element step: element order = lane order, then component order
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        constexpr int UF = 2;
+        for (int n0 = w0 + 4 * lane; n0 < w1; n0 += 256 * UF) {
+            uint4 k[UF];
 #pragma unroll
-        for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+            for (int q = 0; q < UF; ++q) k[q] = n0 + 256 * q < w1 ? k4[(n0 + 256 * q) >> 2] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int q = 0; q < UF; ++q) {
-            const bool in = n0 + 64 * q < w1;
-            cnt_gt += (unsigned)__popcll(__ballot(in && k[q] > T));
-            cnt_eq += (unsigned)__popcll(__ballot(in && k[q] == T));
+            for (int q = 0; q < UF; ++q) {
+                const bool in = n0 + 256 * q < w1;
+                const unsigned c[4] = {k[q].x, k[q].y, k[q].z, k[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cnt_gt += (unsigned)__popcll(__ballot(in && c[e] > T));
+                    cnt_eq += (unsigned)__popcll(__ballot(in && c[e] == T));
+                }
+            }
+        }
+    } else {
+        constexpr int UF = 4;
+        for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
+            unsigned k[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const bool in = n0 + 64 * q < w1;
+                cnt_gt += (unsigned)__popcll(__ballot(in && k[q] > T));
+                cnt_eq += (unsigned)__popcll(__ballot(in && k[q] == T));
+            }
         }
     }
     if (lane == 0) { wsum[0][wave] = cnt_gt; wsum[1][wave] = cnt_eq; }
     __syncthreads();
     unsigned run_gt = 0, run_eq = 0;
     for (int w2 = 0; w2 < wave; ++w2) { run_gt += wsum[0][w2]; run_eq += wsum[1][w2]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
-        unsigned k[UF];
+    if (vec) {
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        constexpr int UF = 2;
+        for (int n0 = w0 + 4 * lane; n0 < w1; n0 += 256 * UF) {
+            uint4 k[UF];
 #pragma unroll
-        for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+            for (int q = 0; q < UF; ++q) k[q] = n0 + 256 * q < w1 ? k4[(n0 + 256 * q) >> 2] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int q = 0; q < UF; ++q) {
-            const int n = n0 + 64 * q;
-            const bool in = n < w1;
-            const bool gt = in && k[q] > T, eq = in && k[q] == T;
-            const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-            const unsigned pre_gt = run_gt + (unsigned)__popcll(bg & below), pre_eq = run_eq + (unsigned)__popcll(be & below);
-            if (gt || (eq && pre_eq < need)) dst[pre_gt + (pre_eq < need ? pre_eq : need)] = n;
-            run_gt += (unsigned)__popcll(bg);
-            run_eq += (unsigned)__popcll(be);
+            for (int q = 0; q < UF; ++q) {
+                const int n = n0 + 256 * q;
+                const bool in = n < w1;
+                const unsigned c[4] = {k[q].x, k[q].y, k[q].z, k[q].w};
+                bool gt[4], eq[4];
+                unsigned long long bg[4], be[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gt[e] = in && c[e] > T;
+                    eq[e] = in && c[e] == T;
+                    bg[e] = __ballot(gt[e]);
+                    be[e] = __ballot(eq[e]);
+                }
+                // winners before this lane's first element: all four components of the lower lanes
+                unsigned pre_gt = run_gt, pre_eq = run_eq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pre_gt += (unsigned)__popcll(bg[e] & below);
+                    pre_eq += (unsigned)__popcll(be[e] & below);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (gt[e] || (eq[e] && pre_eq < need)) dst[pre_gt + (pre_eq < need ? pre_eq : need)] = n + e;
+                    pre_gt += gt[e] ? 1u : 0u;
+                    pre_eq += eq[e] ? 1u : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    run_gt += (unsigned)__popcll(bg[e]);
+                    run_eq += (unsigned)__popcll(be[e]);
+                }
+            }
+        }
+    } else {
+        constexpr int UF = 4;
+        for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
+            unsigned k[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) k[q] = n0 + 64 * q < w1 ? keys[n0 + 64 * q] : 0u;
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int n = n0 + 64 * q;
+                const bool in = n < w1;
+                const bool gt = in && k[q] > T, eq = in && k[q] == T;
+                const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+                const unsigned pre_gt = run_gt + (unsigned)__popcll(bg & below), pre_eq = run_eq + (unsigned)__popcll(be & below);
+                if (gt || (eq && pre_eq < need)) dst[pre_gt + (pre_eq < need ? pre_eq : need)] = n;
+                run_gt += (unsigned)__popcll(bg);
+                run_eq += (unsigned)__popcll(be);
+            }
         }
     }
 }

@@ -389,11 +389,12 @@ def test_resize_normalise_image_sizes_and_extra_channel():
 
 
 # ---- A7: weighted sampling without replacement ------------------------------------------------------------
-def test_sample_without_replacement_is_a_valid_draw():
+@pytest.mark.parametrize("N", [50000, 50001, 49999])  # 16-byte key loads need N % 4 == 0; the others take the scalar path
+def test_sample_without_replacement_is_a_valid_draw(N):
     from gfnet_amd import ops
 
     rng = np.random.default_rng(4)
-    Bt, N, K = 3, 50000, 7000
+    Bt, N, K = 3, N, 7000
     w = rng.uniform(0.0, 1.0, size=(Bt, N)).astype(np.float32)
     w[:, ::7] = 0.0                                   # zero-weight entries must never be drawn while positives remain
     w[0, :100] = 1e6                                  # overwhelming weights are (almost surely) all drawn
