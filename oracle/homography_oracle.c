@@ -103,15 +103,16 @@ static int solve4(const float *pts, const uint32_t idx[4], double H[9]) {
 /* Inlier test of one correspondence: squared reprojection error <= thr2 (OpenCV HomographyEstimatorCallback::
  * computeError followed by the threshold test of RANSAC).  With (X, Y, w) = H (x, y, 1)^T the error is
  * (X/w - u)^2 + (Y/w - v)^2; multiplied through by w^2 the test reads (X - u w)^2 + (Y - v w)^2 <= thr2 w^2 -- no
- * division (w = 0 never passes).  The GPU kernels evaluate exactly this sequence of operations (fp64, no contraction),
- * so inlier counts and masks are bit-identical. */
+ * division (w = 0 never passes).  The sums are written as explicit fused multiply-adds (fma() is exactly rounded whether
+ * libm or the hardware evaluates it): the GPU kernels evaluate exactly this sequence of operations in fp64 -- 12 instead of
+ * 25 instructions per test there -- so inlier counts and masks are bit-identical. */
 static inline int is_inlier(const double H[9], const float *p, double thr2) {
     const double x = p[0], y = p[1], u = p[2], v = p[3];
-    const double w = H[6] * x + H[7] * y + H[8];
-    const double dx = (H[0] * x + H[1] * y + H[2]) - u * w;
-    const double dy = (H[3] * x + H[4] * y + H[5]) - v * w;
+    const double w = fma(H[6], x, fma(H[7], y, H[8]));
+    const double dx = fma(-u, w, fma(H[0], x, fma(H[1], y, H[2])));
+    const double dy = fma(-v, w, fma(H[3], x, fma(H[4], y, H[5])));
     const double w2 = w * w;
-    return dx * dx + dy * dy <= thr2 * w2 && w2 > 0;
+    return fma(dx, dx, dy * dy) <= thr2 * w2 && w2 > 0;
 }
 
 /* cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9): A -> diag, V columns = eigenvectors */
