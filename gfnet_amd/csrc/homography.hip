@@ -226,10 +226,26 @@ struct FinShared {
     int total;
 };
 
+// Sum over the 64 lanes of a wave (returned to every lane, fixed order).  DPP moves on the VALU instead of the ds_bpermute
+// butterfly: a finish pass reduces 36-45 doubles, and 12 LDS-pipe permutes per value were most of its ~9 k cycles.
+//   quad_perm [1,0,3,2], [2,3,0,1]: quad sums; row_half_mirror, row_mirror: sums of 8 and 16 (the groups are uniform by then);
+//   row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int tl = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int th = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(th, tl);  // rows outside ROW_MASK receive +0.0
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // sum K values per thread over the block (fixed order -> reproducible); result in sh.stats-like dst[0..K)
