@@ -84,17 +84,29 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_kernel(const float *__restri
 // are >= 1 from the self term).
 constexpr float kKdeCutoffLog2 = 32.f;
 
+// 16-bit position of a point along a Hilbert curve over the A-image coordinates (8 bits per axis; the B-image position follows
+// it for inliers).  A Z-order (Morton) key was used first: runs of 64 consecutive points that straddle a quadrant boundary
+// of the Z curve have huge bounding boxes and are never culled; the Hilbert curve is continuous, its runs stay compact.
+__device__ __forceinline__ unsigned curve_key16(float4 v) {
+    unsigned x = (unsigned)fminf(fmaxf((v.x + 1.f) * 128.f, 0.f), 255.f);
+    unsigned y = (unsigned)fminf(fmaxf((v.y + 1.f) * 128.f, 0.f), 255.f);
+    unsigned d = 0;
+#pragma unroll
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (!ry) {  // rotate the quadrant
+            if (rx) { x = 255u - x; y = 255u - y; }
+            const unsigned t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
 __global__ __launch_bounds__(256) void kde4_morton_kernel(const float *__restrict__ x, int *__restrict__ keys, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 v = reinterpret_cast<const float4 *>(x)[i];
-    // 8 bits per axis of the A-image position (the B-image position follows it for inliers)
-    const unsigned qx = (unsigned)fminf(fmaxf((v.x + 1.f) * 128.f, 0.f), 255.f);
-    const unsigned qy = (unsigned)fminf(fmaxf((v.y + 1.f) * 128.f, 0.f), 255.f);
-    unsigned key = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) key |= (((qx >> b) & 1u) << (2 * b)) | (((qy >> b) & 1u) << (2 * b + 1));
-    keys[i] = (int)key;
+    keys[i] = (int)curve_key16(reinterpret_cast<const float4 *>(x)[i]);
 }
 
 // Stable sort of one row of points by its 16-bit Morton key, one 1024-thread workgroup per row: two least-significant-
@@ -106,14 +118,7 @@ __global__ __launch_bounds__(256) void kde4_morton_kernel(const float *__restric
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / 64;
 
-__device__ __forceinline__ unsigned morton16(float4 v) {
-    const unsigned qx = (unsigned)fminf(fmaxf((v.x + 1.f) * 128.f, 0.f), 255.f);
-    const unsigned qy = (unsigned)fminf(fmaxf((v.y + 1.f) * 128.f, 0.f), 255.f);
-    unsigned key = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) key |= (((qx >> b) & 1u) << (2 * b)) | (((qy >> b) & 1u) << (2 * b + 1));
-    return key;
-}
+__device__ __forceinline__ unsigned morton16(float4 v) { return curve_key16(v); }  // historical name: the sort key
 
 __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const float *__restrict__ x, float *__restrict__ xsorted,
                                                                         int *__restrict__ perm, unsigned *__restrict__ tmp, int N) {
@@ -122,14 +127,14 @@ __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const fl
     __shared__ unsigned scan[256];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4 *xr = reinterpret_cast<const float4 *>(x) + (size_t)row * N;
-    unsigned *t0 = tmp + (size_t)row * N;  // pass-0 output: (key << 16 | ... ) cannot hold the index; keep index, recompute key
+    unsigned *t0 = tmp + (size_t)row * N;  // pass-0 output: index (24 bits; N <= 65535*16) | high digit of the key << 24
     for (int pass = 0; pass < 2; ++pass) {
         // ---- histogram of this pass's digit
         if (tid < 256) base[tid] = 0;
         __syncthreads();
         for (int n = tid; n < N; n += kSortThreads) {
-            const int src = pass == 0 ? n : (int)t0[n];
-            atomicAdd(&base[(morton16(xr[src]) >> (8 * pass)) & 255u], 1u);
+            const unsigned d = pass == 0 ? morton16(xr[n]) & 255u : t0[n] >> 24;
+            atomicAdd(&base[d], 1u);
         }
         __syncthreads();
         // ---- exclusive scan of 256 counters (one wave, four per lane)
@@ -155,8 +160,13 @@ __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const fl
             __syncthreads();
             const int n = n0 + tid;
             const bool live = n < N;
-            const int src = live ? (pass == 0 ? n : (int)t0[n]) : 0;
-            const unsigned digit = live ? (morton16(xr[src]) >> (8 * pass)) & 255u : 0u;
+            unsigned key = 0, packed = 0;
+            if (live) {
+                if (pass == 0) key = morton16(xr[n]);
+                else packed = t0[n];
+            }
+            const int src = pass == 0 ? n : (int)(packed & 0xFFFFFFu);
+            const unsigned digit = pass == 0 ? key & 255u : packed >> 24;
             // lanes of this wave with the same digit
             unsigned long long peers = __ballot(live);
 #pragma unroll
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const fl
                 for (int w = 0; w < wave; ++w) before += tab[w][digit];
                 const unsigned pos = base[digit] + before + below;
                 if (pass == 0) {
-                    t0[pos] = (unsigned)src;
+                    t0[pos] = (unsigned)src | ((key >> 8) << 24);
                 } else {
                     perm[(size_t)row * N + pos] = src;
                     reinterpret_cast<float4 *>(xsorted)[(size_t)row * N + pos] = xr[src];
