@@ -109,12 +109,15 @@ __global__ __launch_bounds__(256) void kde4_morton_kernel(const float *__restric
     keys[i] = (int)curve_key16(reinterpret_cast<const float4 *>(x)[i]);
 }
 
-// Stable sort of one row of points by its 16-bit Morton key, one 1024-thread workgroup per row: two least-significant-
-// digit passes of 8 bits.  Per pass: digit histogram (LDS atomics), exclusive scan, then the row is walked in chunks of
-// 1024 elements IN ORDER; inside a chunk an element's rank among equal digits is (equal digits in earlier waves, from a
-// [wave][digit] table) + (equal digits in lower lanes of its own wave, from eight ballots), which keeps the sort stable and
-// the result independent of scheduling -- the same permutation a stable library sort gives.  (torch.sort of the 32 x 20000
-// keys took 0.53 ms in 76 merge-sort launches; this takes one launch.)
+// Stable sort of one row of points by its 16-bit curve key, one 1024-thread workgroup per row: two least-significant-digit
+// passes of 8 bits.  Every wave owns one contiguous sixteenth of the row.  Per pass: (A) each wave counts the digits of its
+// segment (LDS atomics on its own row of a [wave][digit] table); (B) one exclusive scan turns the table into the first
+// output position of every (digit, wave) -- digits major, waves minor, which is exactly the stable order; (C) each wave walks
+// its segment again IN ORDER, 64 elements at a time: an element's position is its (digit, wave) cursor + the number of
+// lower lanes with the same digit (eight ballots), and the first lane of every digit group advances the cursor.  Step (C)
+// needs no workgroup barrier (a wave's LDS operations are ordered), so a pass has three barriers in total -- the first
+// version re-synchronised the workgroup four times per 1024 elements and took 0.13 ms; this one takes ~0.03 ms.  The
+// result is the permutation a stable library sort gives (torch.sort of the 32 x 20000 keys: 0.53 ms in 76 launches).
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / 64;
 
@@ -122,26 +125,45 @@ __device__ __forceinline__ unsigned morton16(float4 v) { return curve_key16(v); 
 
 __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const float *__restrict__ x, float *__restrict__ xsorted,
                                                                         int *__restrict__ perm, unsigned *__restrict__ tmp, int N) {
-    __shared__ unsigned base[256];                 // next output position of every digit
-    __shared__ unsigned short tab[kSortWaves][256];  // elements of (wave, digit) in the current chunk
-    __shared__ unsigned scan[256];
+    __shared__ unsigned cur[kSortWaves][256];  // (A) counts, (B)/(C) next output position of (wave, digit)
+    __shared__ unsigned tot[256];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4 *xr = reinterpret_cast<const float4 *>(x) + (size_t)row * N;
     unsigned *t0 = tmp + (size_t)row * N;  // pass-0 output: index (24 bits; N <= 65535*16) | high digit of the key << 24
+    const int per_wave = ((N + kSortWaves - 1) / kSortWaves + 63) & ~63;
+    const int w0 = wave * per_wave, w1 = min(N, w0 + per_wave);
     for (int pass = 0; pass < 2; ++pass) {
-        // ---- histogram of this pass's digit
-        if (tid < 256) base[tid] = 0;
+        for (int e = tid; e < kSortWaves * 256; e += kSortThreads) (&cur[0][0])[e] = 0;
         __syncthreads();
-        for (int n = tid; n < N; n += kSortThreads) {
-            const unsigned d = pass == 0 ? morton16(xr[n]) & 255u : t0[n] >> 24;
-            atomicAdd(&base[d], 1u);
+        // ---- (A) digit counts of this wave's segment
+        constexpr int UF = 4;  // loads in flight per lane: a wave's walk is otherwise one exposed L2 / DRAM round trip per 64 elements
+        for (int n0 = w0 + lane; n0 < w1; n0 += 64 * UF) {
+            float4 pv[UF];
+            unsigned tv[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int n = min(n0 + 64 * q, N - 1);
+                if (pass == 0) pv[q] = xr[n];
+                else tv[q] = t0[n];
+            }
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                if (n0 + 64 * q < w1) atomicAdd(&cur[wave][pass == 0 ? morton16(pv[q]) & 255u : tv[q] >> 24], 1u);
+            }
         }
         __syncthreads();
-        // ---- exclusive scan of 256 counters (one wave, four per lane)
-        if (wave == 0) {
+        // ---- (B) exclusive scan, digits major / waves minor
+        if (tid < 256) {
+            unsigned s = 0;
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) s += cur[w][tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {  // 256 totals, four per lane
             unsigned c[4], s = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { c[q] = base[lane * 4 + q]; s += c[q]; }
+            for (int q = 0; q < 4; ++q) { c[q] = tot[lane * 4 + q]; s += c[q]; }
             unsigned incl = s;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -150,53 +172,57 @@ __global__ __launch_bounds__(kSortThreads) void kde4_morton_sort_kernel(const fl
             }
             unsigned run = incl - s;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { scan[lane * 4 + q] = run; run += c[q]; }
+            for (int q = 0; q < 4; ++q) { tot[lane * 4 + q] = run; run += c[q]; }
         }
         __syncthreads();
-        if (tid < 256) base[tid] = scan[tid];
-        // ---- ordered scatter
-        for (int n0 = 0; n0 < N; n0 += kSortThreads) {
-            for (int e = tid; e < kSortWaves * 256; e += kSortThreads) (&tab[0][0])[e] = 0;
-            __syncthreads();
-            const int n = n0 + tid;
-            const bool live = n < N;
-            unsigned key = 0, packed = 0;
-            if (live) {
-                if (pass == 0) key = morton16(xr[n]);
-                else packed = t0[n];
-            }
-            const int src = pass == 0 ? n : (int)(packed & 0xFFFFFFu);
-            const unsigned digit = pass == 0 ? key & 255u : packed >> 24;
-            // lanes of this wave with the same digit
-            unsigned long long peers = __ballot(live);
+        if (tid < 256) {
+            unsigned run = tot[tid];
 #pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const unsigned long long m = __ballot((digit >> bit) & 1u);
-                peers &= ((digit >> bit) & 1u) ? m : ~m;
+            for (int w = 0; w < kSortWaves; ++w) {
+                const unsigned c = cur[w][tid];
+                cur[w][tid] = run;
+                run += c;
             }
-            const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-            if (live && below == 0) tab[wave][digit] = (unsigned short)__popcll(peers);
-            __syncthreads();
-            if (live) {
-                unsigned before = 0;
-                for (int w = 0; w < wave; ++w) before += tab[w][digit];
-                const unsigned pos = base[digit] + before + below;
-                if (pass == 0) {
-                    t0[pos] = (unsigned)src | ((key >> 8) << 24);
-                } else {
-                    perm[(size_t)row * N + pos] = src;
-                    reinterpret_cast<float4 *>(xsorted)[(size_t)row * N + pos] = xr[src];
-                }
-            }
-            __syncthreads();
-            if (tid < 256) {
-                unsigned tot = 0;
-#pragma unroll
-                for (int w = 0; w < kSortWaves; ++w) tot += tab[w][tid];
-                base[tid] += tot;
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        // ---- (C) ordered scatter of this wave's segment
+        for (int nb = w0; nb < w1; nb += 64 * UF) {
+            float4 pv[UF];
+            unsigned tv[UF];
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int n = min(nb + 64 * q + lane, N - 1);
+                if (pass == 0) pv[q] = xr[n];
+                else tv[q] = t0[n];
+            }
+#pragma unroll
+            for (int q = 0; q < UF; ++q) {
+                const int n = nb + 64 * q + lane;
+                const bool live = n < w1;
+                const unsigned key = pass == 0 ? morton16(pv[q]) : 0u, packed = pass == 0 ? 0u : tv[q];
+                const int src = pass == 0 ? n : (int)(packed & 0xFFFFFFu);
+                const unsigned digit = live ? (pass == 0 ? key & 255u : packed >> 24) : 0u;
+                unsigned long long peers = __ballot(live);  // lanes of this wave with the same digit
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const unsigned long long m = __ballot((digit >> bit) & 1u);
+                    peers &= ((digit >> bit) & 1u) ? m : ~m;
+                }
+                const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+                if (live) {
+                    const unsigned pos = cur[wave][digit] + below;
+                    if (pass == 0) {
+                        t0[pos] = (unsigned)src | ((key >> 8) << 24);
+                    } else {
+                        perm[(size_t)row * N + pos] = src;
+                        reinterpret_cast<float4 *>(xsorted)[(size_t)row * N + pos] = xr[src];
+                    }
+                }
+                // all lanes have read the cursor (the reads above precede this write in the wave's LDS order)
+                if (live && below == 0) cur[wave][digit] += (unsigned)__popcll(peers);
+            }
+        }
+        __syncthreads();  // pass 1 reads what other waves wrote to t0
     }
 }
 
