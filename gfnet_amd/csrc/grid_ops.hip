@@ -331,14 +331,16 @@ __global__ __launch_bounds__(256) void flow_update_kernel(const float *__restric
         const long r = idx - (long)b * GG;
         const float *dl = dflow + (size_t)b * dflow_bs + r;
         float dx = scale * (dl[0] / div_x), dy = scale * (dl[GG] / div_y);  // network.py:262-263
-        float *pp = disp_prev + (size_t)b * 2 * GG + r;
+        float *pp = disp_prev ? disp_prev + (size_t)b * 2 * GG + r : nullptr;  // NULL: single-iteration scale, nothing to carry
         if (zero_small) {  // network.py:256,264-265
             const float px = first ? 1e-7f : pp[0], py = first ? 1e-7f : pp[GG];
             if (fabsf(dx - px) / fabsf(px) < 1e-6f) dx = 0.f;
             if (fabsf(dy - py) / fabsf(py) < 1e-6f) dy = 0.f;
         }
-        pp[0] = dx;
-        pp[GG] = dy;
+        if (pp) {
+            pp[0] = dx;
+            pp[GG] = dy;
+        }
         const size_t o = (size_t)b * 2 * GG + r;
         flow_out[o] = flow_in[o] + dx;
         flow_out[o + GG] = flow_in[o + GG] + dy;
@@ -469,8 +471,8 @@ GFN_EXPORT int gfn_flow_update_out_fwd(const float *flow_in, const float *cert_i
                                        const float *dflow, int64_t dflow_bs, const float *dcert, int64_t dcert_bs, float *disp_prev,
                                        int B, int G, int scale, int W0, int H0, int zero_small, int first_iteration,
                                        gfn_stream_t stream) {
-    if (!flow_in || !cert_in || !flow_out || !cert_out || !dflow || !dcert || !disp_prev || B < 0 || G <= 0 || W0 <= 0 || H0 <= 0 ||
-        dflow_bs < 2L * G * G || dcert_bs < (long)G * G)
+    if (!flow_in || !cert_in || !flow_out || !cert_out || !dflow || !dcert || B < 0 || G <= 0 || W0 <= 0 || H0 <= 0 ||
+        dflow_bs < 2L * G * G || dcert_bs < (long)G * G || (!disp_prev && !first_iteration))
         return gfn::fail(GFN_ERR_INVALID_ARG, "flow_update_out: bad argument");
     if (B == 0) return GFN_OK;
     hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((long)B * G * G)), dim3(256), 0, (hipStream_t)stream, flow_in, cert_in, flow_out,

@@ -234,7 +234,7 @@ class GFNet(nn.Module):
                     flow = ops.corr_softargmax(f0, f1, symmetric=symmetric)                      # :251-252
                     certainty = torch.zeros((flow.shape[0], 1) + tuple(flow.shape[2:]), device=flow.device)  # :253
             corresps[scale] = {}
-            disp_prev = torch.empty_like(flow)
+            disp_prev = torch.empty_like(flow) if num_itr[idx] > 1 else None  # carried between the iterations of one scale
             for itr in range(num_itr[idx]):
                 d_flow, d_cert, _ = self.conv_refiner[scale](num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
                 # each iteration's result is kept (corresps): out-of-place update straight from the refiner's outputs

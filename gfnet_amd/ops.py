@@ -175,13 +175,17 @@ def _plane_view(t, planes, G):
 
 def flow_update(flow, certainty, d_flow, d_cert, disp_prev, scale, W0, H0, zero_small=True, first_iteration=True):
     """model/network.py:262-268 out of place: returns (flow + displacement(d_flow), certainty + d_cert) as new tensors (the
-    reference keeps every iteration's result); d_flow (B,2,G,G) / d_cert (B,1,G,G) may be channel slices of one tensor."""
-    dev = require_gpu(flow, certainty, d_flow, d_cert, disp_prev)
+    reference keeps every iteration's result); d_flow (B,2,G,G) / d_cert (B,1,G,G) may be channel slices of one tensor.
+    disp_prev=None (first iteration of a scale that has only one): the displacement is not stored."""
+    dev = require_gpu(flow, certainty, d_flow, d_cert, *(() if disp_prev is None else (disp_prev,)))
     B, _, G, _ = flow.shape
-    if tuple(certainty.shape) != (B, 1, G, G) or tuple(disp_prev.shape) != (B, 2, G, G) or tuple(d_flow.shape) != (B, 2, G, G) or \
-            tuple(d_cert.shape) != (B, 1, G, G):
+    if tuple(certainty.shape) != (B, 1, G, G) or tuple(d_flow.shape) != (B, 2, G, G) or tuple(d_cert.shape) != (B, 1, G, G) or \
+            (disp_prev is not None and tuple(disp_prev.shape) != (B, 2, G, G)):
         raise ValueError("flow_update: inconsistent shapes")
-    if disp_prev.dtype != torch.float32 or not disp_prev.is_contiguous():
+    if disp_prev is None:
+        if not first_iteration:
+            raise ValueError("flow_update: disp_prev=None is only valid for the first (and only) iteration of a scale")
+    elif disp_prev.dtype != torch.float32 or not disp_prev.is_contiguous():
         raise ValueError("flow_update: disp_prev must be contiguous fp32 (updated in place)")
     fi, ci = f32c(flow), f32c(certainty)
     df, df_bs = _plane_view(d_flow, 2, G)

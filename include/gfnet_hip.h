@@ -149,7 +149,8 @@ int gfn_flow_update_fwd(float *flow, float *certainty, const float *delta, int64
                         int scale, int W0, int H0, int zero_small, int first_iteration, gfn_stream_t stream);
 /* The same step out of place and with the refiner's two outputs as they come (network.py:259-268 keeps every iteration's
  * flow and certainty): flow_out = flow_in + disp(dflow), cert_out = cert_in + dcert; dflow (B,>=2,G,G) with batch stride
- * dflow_bs, dcert (B,>=1,G,G) with dcert_bs.  Outputs may alias the inputs. */
+ * dflow_bs, dcert (B,>=1,G,G) with dcert_bs.  Outputs may alias the inputs.  disp_prev may be NULL when first_iteration is
+ * set and no further iteration follows at this scale (the displacement is then not stored). */
 int gfn_flow_update_out_fwd(const float *flow_in, const float *cert_in, float *flow_out, float *cert_out, const float *dflow,
                             int64_t dflow_bs, const float *dcert, int64_t dcert_bs, float *disp_prev, int B, int G, int scale,
                             int W0, int H0, int zero_small, int first_iteration, gfn_stream_t stream);

@@ -179,6 +179,11 @@ def test_flow_update_vs_oracle():
     tp1 = torch.zeros(B, 2, G, G, device="cuda")
     fo2, co2 = ops.flow_update(tf0, tc0, td[:, :2].contiguous(), td[:, 2:3].contiguous(), tp1, 8, 448, 448, first_iteration=True)
     assert torch.equal(fo, fo2) and torch.equal(co, co2) and torch.equal(tp0, tp1)
+    # a scale with a single iteration carries nothing: disp_prev=None gives the same flow / certainty
+    fo3, co3 = ops.flow_update(tf0, tc0, td[:, :2], td[:, 2:3], None, 8, 448, 448, first_iteration=True)
+    assert torch.equal(fo, fo3) and torch.equal(co, co3)
+    with pytest.raises(ValueError):
+        ops.flow_update(tf0, tc0, td[:, :2], td[:, 2:3], None, 8, 448, 448, first_iteration=False)
 
 
 @pytest.mark.parametrize("tag,symmetric,attenuate", [("sym_up_att", True, True), ("plain", False, False),
