@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
                         rb += vb[k][e].x * sb.w[2 * e];
                         rb += vb[k][e].y * sb.w[2 * e + 1];
                     }
-                    (o + (size_t)(c0 + k) * GG)[cell] = ra;
-                    (o + (size_t)(C + c0 + k) * GG)[cell] = rb;
+                    __builtin_nontemporal_store(ra, o + (size_t)(c0 + k) * GG + cell);
+                    __builtin_nontemporal_store(rb, o + (size_t)(C + c0 + k) * GG + cell);
                 }
             }
         }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
     }
     // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
     const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
-    for (int k = 0; k < Dd; ++k) (o + (size_t)(2 * C + k) * GG)[cell] = dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k];
+    for (int k = 0; k < Dd; ++k) __builtin_nontemporal_store(dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k], o + (size_t)(2 * C + k) * GG + cell);
 }
 
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
