@@ -687,7 +687,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                         v += top[kx + 1] * (wx1[kx] * wy0);
                         v += bot[kx] * (wx0 * wy1);
                         v += bot[kx + 1] * (wx1[kx] * wy1);
-                        ok[(size_t)kx * cs] = v * p.inv_sqrt_c;
+                        __builtin_nontemporal_store(v * p.inv_sqrt_c, ok + (size_t)kx * cs);  // streamed: nothing on the hot path reads it back
                     }
                 }
             }
