@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
                         rb += vb[k][e].x * sb.w[2 * e];
                         rb += vb[k][e].y * sb.w[2 * e + 1];
                     }
-                    __builtin_nontemporal_store(ra, o + (size_t)(c0 + k) * GG + cell);
+                    (o + (size_t)(c0 + k) * GG)[cell] = ra;  // read back at once as the local correlation's f0: stays cached
                     __builtin_nontemporal_store(rb, o + (size_t)(C + c0 + k) * GG + cell);
                 }
             }
