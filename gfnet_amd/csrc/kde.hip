@@ -26,17 +26,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (its term is exp2(-inf) = 0).
 __global__ __launch_bounds__(256) void kde4_prescale_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                             float *__restrict__ xs, float *__restrict__ ys, int N,
-                                                            int M, long y_rs, long y_bs, float scale, int Bt) {
+                                                            int M, long y_rs, long y_bs, float scale, int Bt, int round_fp16 = 0) {
     const int Mp = (M + 1) & ~1;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nx = (long)Bt * N * 4, ny = (long)Bt * Mp * 4;
-    if (idx < nx) xs[idx] = x[idx] * scale;
+    // round_fp16: the reference hands kde() fp16 coordinates (network.py:408, kde.py:6); rounding here saves the caller two
+    // elementwise launches
+    auto rnd = [&](float v) { return round_fp16 ? (float)(_Float16)v : v; };  // round to nearest even, like torch .half()
+    if (idx < nx) xs[idx] = rnd(x[idx]) * scale;
     if (idx < ny) {
         const int bt = (int)(idx / ((long)Mp * 4));
         const long r = idx - (long)bt * Mp * 4;
         const int pair = (int)(r >> 3), d = (int)((r >> 1) & 3), which = (int)(r & 1);
         const int m = pair * 2 + which;
-        ys[idx] = (m < M) ? y[(size_t)bt * y_bs + (size_t)m * y_rs + d] * scale : 1e18f;
+        ys[idx] = (m < M) ? rnd(y[(size_t)bt * y_bs + (size_t)m * y_rs + d]) * scale : 1e18f;
     }
 }
 
@@ -612,13 +615,14 @@ __global__ __launch_bounds__(256) void kde_reduce_kernel(const float *__restrict
 
 // symmetric kernel: density = row sums (split-M partials, fixed order) + column sums (fixed point)
 __global__ __launch_bounds__(256) void kde_combine_kernel(const float *__restrict__ part, const unsigned long long *__restrict__ colacc,
-                                                          float *__restrict__ out, int N, int MS, int Bt) {
+                                                          const int *__restrict__ perm, float *__restrict__ out, int N, int MS, int Bt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)Bt * N) return;
     const int bt = (int)(idx / N), n = (int)(idx - (long)bt * N);
     float s = 0.f;
     for (int k = 0; k < MS; ++k) s += part[((size_t)bt * MS + k) * N + n];
-    out[idx] = s + (float)((double)colacc[idx] * (1.0 / 1099511627776.0));
+    if (colacc) s += (float)((double)colacc[idx] * (1.0 / 1099511627776.0));
+    out[perm ? (size_t)bt * N + perm[idx] : (size_t)idx] = s;  // perm: back to the caller's order (sorted position -> original index)
 }
 
 // GFNet.sample's elementwise steps (model/network.py:391-393, 409-410)
@@ -628,10 +632,11 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 }
 
 __global__ __launch_bounds__(256) void balance_kernel(const float *__restrict__ density, float *__restrict__ p, long n,
-                                                      float min_density, float floor_p) {
+                                                      float min_density, float floor_p, int round_fp16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const float d = density[i];
+        float d = density[i];
+        if (round_fp16) d = (float)(_Float16)d;  // kde(half=True) returns fp16 (kde.py:13)
         p[i] = d < min_density ? floor_p : 1.f / (d + 1.f);
     }
 }
@@ -646,12 +651,12 @@ GFN_EXPORT int gfn_threshold_certainty(const float *certainty, float *out, int64
     return gfn::check_launch("threshold_kernel");
 }
 
-GFN_EXPORT int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p,
+GFN_EXPORT int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p, int round_fp16,
                                    gfn_stream_t stream) {
     if (!density || !p || n < 0) return gfn::fail(GFN_ERR_INVALID_ARG, "balance_weights: bad argument");
     if (n == 0) return GFN_OK;
     hipLaunchKernelGGL(balance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, density, p,
-                       (long)n, min_density, floor_p);
+                       (long)n, min_density, floor_p, round_fp16);
     return gfn::check_launch("balance_kernel");
 }
 
@@ -683,8 +688,8 @@ GFN_EXPORT int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M) {
 
 // Density of spatially sorted 4-D points (see kde4_culled_kernel): x (Bt,N,4), y (Bt,M,4), both in
 // the order of their gfn_kde_morton_keys; out (Bt,N) in the order of x.
-GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, int N, int M, double std,
-                                      float *scratch, int64_t scratch_floats, gfn_stream_t stream) {
+GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out, const int *perm, int Bt, int N, int M, double std,
+                                      int round_fp16, float *scratch, int64_t scratch_floats, gfn_stream_t stream) {
     if (!x || !y || !out || !scratch) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_sorted: null pointer");
     if (Bt < 0 || N < 0 || M <= 0 || !(std > 0) || Bt > 65535) return gfn::fail(GFN_ERR_INVALID_ARG, "kde_sorted: bad argument");
     if (scratch_floats < gfn_kde_sorted_scratch_floats(Bt, N, M) || ((uintptr_t)scratch & 15) || ((uintptr_t)x & 15))
@@ -698,14 +703,14 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
     float *part = box32 + (int64_t)Bt * nblk * 16;
     const long tot = (long)Bt * 4 * (N > Mp ? N : Mp);
     hipLaunchKernelGGL(kde4_prescale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, y, xs, ys, N, M, 4L,
-                       (long)M * 4, scale, Bt);
+                       (long)M * 4, scale, Bt, round_fp16);
     hipLaunchKernelGGL(kde4_bbox_kernel, dim3((unsigned)(((long)Bt * nblk + 3) / 4)), dim3(256), 0, s, ys, box, box32, M, Mp, Bt);
     int MS = 1;
     {   // same rule as the dense kernel: enough workgroups for the chip, at least 8 blocks of points per split
         const long blocks = (long)Bt * ((N + kKdeThreads - 1) / kKdeThreads);
         while (blocks * MS < 2048 && nblk / (MS * 2) >= 8 && MS < 32) MS *= 2;
     }
-    float *dst = MS > 1 ? part : out;
+    float *dst = (MS > 1 || perm) ? part : out;  // perm: results leave through the combine kernel, in the caller's order
     static const bool valu_only = getenv("GFN_KDE_VALU") != nullptr;  // experiments: the difference-form kernel
     static const bool no_sym = getenv("GFN_KDE_NOSYM") != nullptr;    // experiments: full N x N evaluation
     const bool sym = x == y && N == M && !no_sym;
@@ -729,17 +734,17 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
                                bop, box32, part, colacc, N, Mp, NT, MT, tile_cull);
             if (int e = gfn::check_launch("kde4_mfma_kernel")) return e;
             const long total = (long)Bt * N;
-            hipLaunchKernelGGL(kde_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, colacc, out, N, MS, Bt);
+            hipLaunchKernelGGL(kde_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, colacc, perm, out, N, MS, Bt);
             return gfn::check_launch("kde_combine_kernel");
         }
         hipLaunchKernelGGL(kde4_mfma_kernel<false>, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, aop, bop,
                            box32, dst, nullptr, N, Mp, NT, MT, tile_cull);
         if (int e = gfn::check_launch("kde4_mfma_kernel")) return e;
     }
-    if (MS > 1) {
+    if (MS > 1 || perm) {
         const long total = (long)Bt * N;
-        hipLaunchKernelGGL(kde_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, out, N, MS, Bt);
-        return gfn::check_launch("kde_reduce_kernel");
+        hipLaunchKernelGGL(kde_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, nullptr, perm, out, N, MS, Bt);
+        return gfn::check_launch("kde_combine_kernel");
     }
     return GFN_OK;
 }

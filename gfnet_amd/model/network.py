@@ -355,8 +355,8 @@ def sample_batched(model, warp, certainty, num=5_000, sampler="hip"):
     gc = torch.gather(c, 1, good)
     if "balanced" not in model.sample_mode:
         return gm, gc
-    density = ops.kde_density(gm.half().float(), std=0.1)                            # half inputs, fp32 sums
-    p = ops.balance_weights(density.half().float())
+    density = ops.kde_density(gm, std=0.1, round_fp16=True)                          # half inputs, fp32 sums
+    p = ops.balance_weights(density, round_fp16=True)
     n2 = min(num, n1)
     bal = draw(p, n2)
     return torch.gather(gm, 1, bal[..., None].expand(B, n2, 4)).contiguous(), torch.gather(gc, 1, bal)

@@ -215,8 +215,9 @@ def match_post(flow, certainty, cert16=None, symmetric=True):
     return warp, cout
 
 
-def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None):
+def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None, round_fp16=False):
     """sum_m exp(-|x_n - y_m|^2/(2 std^2)); x (N,D) or (Bt,N,D); y defaults to x.  fp32.
+    round_fp16: coordinates rounded to fp16 first (what GFNet.sample hands to kde(); sums stay fp32).
     cull (default: automatic for 4-D points, N >= 4096): sort the points along a Morton curve of the
     A-image coordinates and skip blocks of reference points beyond 6.7 std (terms < 2^-32)."""
     dev = require_gpu(x, y)
@@ -241,8 +242,12 @@ def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None):
         if y_row_stride is not None:
             ys = ys[:, ::rs // D].contiguous()
         same = y is None and y_row_stride is None
-        out = _kde_culled(xs, xs if same else ys, std, same, dev)
+        out = _kde_culled(xs, xs if same else ys, std, same, dev, round_fp16)
         return out[0] if squeeze else out
+    if round_fp16:  # only the culled path rounds on the device
+        same_t = ys is xs
+        xs = xs.half().float()
+        ys = xs if same_t else ys.half().float()
     out = torch.empty((Bt, N), device=dev, dtype=torch.float32)
     nscr = int(_L().gfn_kde_scratch_floats(Bt, N, M, D))
     scratch = torch.empty((max(nscr, 4),), device=dev, dtype=torch.float32)
@@ -251,7 +256,7 @@ def kde_density(x, y=None, std=0.1, y_row_stride=None, cull=None):
     return out[0] if squeeze else out
 
 
-def _morton_sorted(pts, dev):
+def _morton_sorted(pts, dev, long_perm=True):
     """(sorted points, permutation): rows stably ordered by the Morton key of their A-image position (one HIP launch:
     in-LDS two-pass radix sort per row, the same permutation as torch.sort(keys, stable=True))."""
     Bt, N, _ = pts.shape
@@ -260,21 +265,20 @@ def _morton_sorted(pts, dev):
     perm = torch.empty((Bt, N), device=dev, dtype=torch.int32)
     tmp = torch.empty((Bt, N), device=dev, dtype=torch.int32)
     check(_L().gfn_kde_morton_sort(ptr(pts), ptr(out), ptr(perm), ptr(tmp), Bt, N, stream_ptr(dev)), "gfn_kde_morton_sort")
-    return out, perm.long()
+    return out, (perm.long() if long_perm else perm)
 
 
-def _kde_culled(xs, ys, std, same, dev):
+def _kde_culled(xs, ys, std, same, dev, round_fp16=False):
     Bt, N, _ = xs.shape
     M = ys.shape[1]
-    xsort, perm = _morton_sorted(xs, dev)
-    ysort = xsort if same else _morton_sorted(ys, dev)[0]
-    dens = torch.empty((Bt, N), device=dev, dtype=torch.float32)
+    xsort, perm = _morton_sorted(xs, dev, long_perm=False)
+    ysort = xsort if same else _morton_sorted(ys, dev, long_perm=False)[0]
+    out = torch.empty((Bt, N), device=dev, dtype=torch.float32)
     nscr = int(_L().gfn_kde_sorted_scratch_floats(Bt, N, M))
     scratch = torch.empty((nscr,), device=dev, dtype=torch.float32)
-    check(_L().gfn_kde_density_sorted(ptr(xsort), ptr(ysort), ptr(dens), Bt, N, M, float(std), ptr(scratch), nscr,
+    # perm: the densities are written straight back in the caller's order
+    check(_L().gfn_kde_density_sorted(ptr(xsort), ptr(ysort), ptr(out), ptr(perm), Bt, N, M, float(std), 1 if round_fp16 else 0, ptr(scratch), nscr,
                                       stream_ptr(dev)), "gfn_kde_density_sorted")
-    out = torch.empty_like(dens)
-    out.scatter_(1, perm, dens)  # back to the caller's order
     return out
 
 
@@ -287,12 +291,13 @@ def threshold_certainty(certainty, thresh):
     return out
 
 
-def balance_weights(density, min_density=10.0, floor_p=1e-7):
-    """p = 1/(density+1); p[density < 10] = 1e-7 (model/network.py:409-410)."""
+def balance_weights(density, min_density=10.0, floor_p=1e-7, round_fp16=False):
+    """p = 1/(density+1); p[density < 10] = 1e-7 (model/network.py:409-410).  round_fp16: the density is rounded to fp16
+    first, as kde(half=True) returns it."""
     dev = require_gpu(density)
     d = f32c(density)
     p = torch.empty_like(d)
-    check(_L().gfn_balance_weights(ptr(d), ptr(p), d.numel(), float(min_density), float(floor_p), stream_ptr(dev)),
+    check(_L().gfn_balance_weights(ptr(d), ptr(p), d.numel(), float(min_density), float(floor_p), 1 if round_fp16 else 0, stream_ptr(dev)),
           "gfn_balance_weights")
     return p
 

@@ -177,22 +177,26 @@ int gfn_kde_density(const float *x, const float *y, float *out, int Bt, int N, i
 
 /* Spatially culled KDE for 4-D matches (same sum as gfn_kde_density up to terms below 2^-32): the
  * caller orders x and y by gfn_kde_morton_keys (any stable sort of the int keys) and passes the
- * sorted arrays; out is in the order of the sorted x.  scratch: gfn_kde_sorted_scratch_floats().
+ * sorted arrays; out is in the order of the sorted x (or the original one, see perm).  scratch: gfn_kde_sorted_scratch_floats().
  * Blocks of 64 reference points farther than 6.7 std from a wave's 64 queries are skipped. */
 int gfn_kde_morton_keys(const float *x, int *keys, int64_t n, gfn_stream_t stream);
 /* The order itself: rows of x (Bt,N,4) stably sorted by their Morton key, one launch.  x_sorted (Bt,N,4),
  * perm (Bt,N): x_sorted[b][i] = x[b][perm[b][i]]; scratch: Bt*N ints. */
 int gfn_kde_morton_sort(const float *x, float *x_sorted, int *perm, int *scratch, int Bt, int N, gfn_stream_t stream);
 int64_t gfn_kde_sorted_scratch_floats(int Bt, int N, int M);
-int gfn_kde_density_sorted(const float *x, const float *y, float *out, int Bt, int N, int M, double std, float *scratch,
-                           int64_t scratch_floats, gfn_stream_t stream);
+/* perm (Bt,N) from gfn_kde_morton_sort of x, or NULL: with it the densities are written in the caller's original order
+ * (out[b][perm[b][i]] = density of x_sorted[b][i]); without it, in the sorted order. */
+int gfn_kde_density_sorted(const float *x, const float *y, float *out, const int *perm, int Bt, int N, int M, double std,
+                           int round_fp16, float *scratch, int64_t scratch_floats, gfn_stream_t stream);
+/* round_fp16: coordinates rounded to fp16 before use, as GFNet.sample hands them to kde() (network.py:408, kde.py:6). */
 
 /* GFNet.sample's elementwise steps (model/network.py:385-414):
  *   gfn_threshold_certainty: out = certainty > thresh ? 1 : certainty            (:391-393)
  *   gfn_balance_weights:     p = density < min_density ? floor_p : 1/(density+1)  (:409-410; 10, 1e-7)
  * (the two torch.multinomial draws stay with torch's generator, as in the reference). */
 int gfn_threshold_certainty(const float *certainty, float *out, int64_t n, float thresh, gfn_stream_t stream);
-int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p, gfn_stream_t stream);
+int gfn_balance_weights(const float *density, float *p, int64_t n, float min_density, float floor_p, int round_fp16,
+                        gfn_stream_t stream);  /* round_fp16: density rounded to fp16 first (kde(half=True) returns fp16, kde.py:13) */
 
 /* Weighted sampling without replacement -- the two torch.multinomial(p, num_samples, replacement=False) draws of
  * GFNet.sample (model/network.py:400-402, 411-413).  Exponential race like torch's implementation (key = w / Exp(1),

@@ -358,6 +358,13 @@ def test_kde_symmetric_path_is_deterministic_and_matches_oracle(Bt, N):
     # same points handed in as a separate reference set: the full N x M kernel, same densities
     other = host(ops.kde_density(xd, xd.clone(), std=0.1, cull=True))
     np.testing.assert_allclose(other, first, rtol=2e-5)
+    # fp16 rounding of the coordinates / of the density on the device == rounding in torch beforehand (GFNet.sample's use)
+    r1 = ops.kde_density(xd, std=0.1, cull=True, round_fp16=True)
+    r2 = ops.kde_density(xd.half().float(), std=0.1, cull=True)
+    np.testing.assert_allclose(host(r1), host(r2), rtol=2e-5)  # same values; the curve keys see unrounded points, so the order of the sums differs
+    assert torch.equal(ops.kde_density(xd[:, :500], std=0.1, cull=False, round_fp16=True),
+                       ops.kde_density(xd[:, :500].half().float(), std=0.1, cull=False))
+    assert torch.equal(ops.balance_weights(r1, round_fp16=True), ops.balance_weights(r1.half().float()))
 
 
 # ---- N3 image resize + normalise ----------------------------------------------------------------------
