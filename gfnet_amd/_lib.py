@@ -37,7 +37,8 @@ _SIGNATURES = {
     "gfn_kde_density_sorted": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_double, c_int, c_vp, c_i64, c_vp],
     "gfn_threshold_certainty": [c_vp, c_vp, c_i64, c_float, c_vp],
     "gfn_balance_weights": [c_vp, c_vp, c_i64, c_float, c_float, c_int, c_vp],
-    "gfn_sample_without_replacement": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp],
+    "gfn_sample_without_replacement": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_float, c_vp],
+    "gfn_gather_matches": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp],
     "gfn_convert_matches": [c_vp, c_vp, c_i64] + [c_float] * 4 + [c_vp],
     "gfn_homography_ransac": [c_vp, c_int, c_int, c_double, c_int, ctypes.c_uint64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_i64, c_vp],

@@ -27,14 +27,16 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // the top 11 key bits (the first radix-select pass) -- in LDS, flushed with one global atomic per occupied bin.
 constexpr int kKeysPerBlock = 8192;
 __global__ __launch_bounds__(256) void race_keys_kernel(const float *__restrict__ w, long w_rs, unsigned *__restrict__ keys,
-                                                        unsigned *__restrict__ hist1, int N, int blocks_per_row, uint64_t seed) {
+                                                        unsigned *__restrict__ hist1, int N, int blocks_per_row, uint64_t seed,
+                                                        float one_above) {
     __shared__ unsigned hist[2048];
     const int row = blockIdx.x / blocks_per_row, chunk = blockIdx.x - row * blocks_per_row;
     for (int e = threadIdx.x; e < 2048; e += 256) hist[e] = 0;
     __syncthreads();
     const int i0 = chunk * kKeysPerBlock, i1 = min(N, i0 + kKeysPerBlock);
     for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-        const float wi = w[(size_t)row * w_rs + i];
+        float wi = w[(size_t)row * w_rs + i];
+        wi = wi > one_above ? 1.f : wi;  // GFNet.sample's certainty threshold (network.py:391-393); +inf = off
         const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)(unsigned)row << 32) | (unsigned)i));
         const float u = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-08f;  // (0, 1], 24 bits
         const float e = -__logf(u);                                                      // Exp(1); 0 only for u == 1
@@ -252,10 +254,37 @@ __global__ __launch_bounds__(kSelThreads) void race_select_kernel(const unsigned
     }
 }
 
+// GFNet.sample's gathers (network.py:403-404, 414): om[b][i] = m[b][idx[b][i]] (rows of 4 floats), oc[b][i] = c[b][idx[b][i]]
+// with the certainty threshold applied on the way (c > one_above -> 1; +inf = off).
+__global__ __launch_bounds__(256) void gather_matches_kernel(const float4 *__restrict__ m, const float *__restrict__ c,
+                                                             const long long *__restrict__ idx, float4 *__restrict__ om,
+                                                             float *__restrict__ oc, int N, int K, long total, float one_above) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / K;
+    const long src = b * N + idx[i];
+    om[i] = m[src];
+    const float cv = c[src];
+    oc[i] = cv > one_above ? 1.f : cv;
+}
+
 }  // namespace
 
+GFN_EXPORT int gfn_gather_matches(const float *matches, const float *certainty, const int64_t *idx, float *out_matches,
+                                  float *out_certainty, int Bt, int N, int K, float one_above, gfn_stream_t stream) {
+    if (!matches || !certainty || !idx || !out_matches || !out_certainty || Bt < 0 || N <= 0 || K < 0 ||
+        (((uintptr_t)matches | (uintptr_t)out_matches) & 15))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "gather_matches: bad argument");
+    const long total = (long)Bt * K;
+    if (total == 0) return GFN_OK;
+    hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(matches), certainty, reinterpret_cast<const long long *>(idx),
+                       reinterpret_cast<float4 *>(out_matches), out_certainty, N, K, total, one_above);
+    return gfn::check_launch("gather_matches_kernel");
+}
+
 GFN_EXPORT int gfn_sample_without_replacement(const float *weights, int64_t row_stride, int64_t *out, int *scratch, int Bt, int N, int K,
-                                              uint64_t seed, gfn_stream_t stream) {
+                                              uint64_t seed, float one_above, gfn_stream_t stream) {
     if (!weights || !out || !scratch || Bt < 0 || N <= 0 || K <= 0 || row_stride < N)
         return gfn::fail(GFN_ERR_INVALID_ARG, "sample_without_replacement: bad argument");
     if (K > N) return gfn::fail(GFN_ERR_INVALID_ARG, "sample_without_replacement: cannot draw %d of %d without replacement", K, N);
@@ -267,7 +296,7 @@ GFN_EXPORT int gfn_sample_without_replacement(const float *weights, int64_t row_
     if (hipMemsetAsync(hist1, 0, sizeof(unsigned) * 2048 * (size_t)Bt, s) != hipSuccess)
         return gfn::fail(GFN_ERR_LAUNCH, "sample_without_replacement: memset failed");
     const int bpr = (N + kKeysPerBlock - 1) / kKeysPerBlock;
-    hipLaunchKernelGGL(race_keys_kernel, dim3((unsigned)(Bt * bpr)), dim3(256), 0, s, weights, (long)row_stride, keys, hist1, N, bpr, seed);
+    hipLaunchKernelGGL(race_keys_kernel, dim3((unsigned)(Bt * bpr)), dim3(256), 0, s, weights, (long)row_stride, keys, hist1, N, bpr, seed, one_above);
     if (int e = gfn::check_launch("race_keys_kernel")) return e;
     hipLaunchKernelGGL(race_select_kernel, dim3(Bt), dim3(kSelThreads), 0, s, keys, hist1, reinterpret_cast<long long *>(out), N, K);
     return gfn::check_launch("race_select_kernel");

@@ -344,21 +344,27 @@ def sample_batched(model, warp, certainty, num=5_000, sampler="hip"):
     B = warp.shape[0]
     m = warp.reshape(B, -1, 4)
     c = certainty.reshape(B, -1)
-    if "threshold" in model.sample_mode:
-        c = ops.threshold_certainty(c, model.sample_thresh)
     expansion = 4 if "balanced" in model.sample_mode else 1
     n1 = min(expansion * num, c.shape[1])
-    draw = ops.sample_without_replacement if sampler == "hip" else \
-        (lambda w, k: torch.multinomial(w, num_samples=k, replacement=False))
-    good = draw(c, n1)                                                               # (B,n1)
-    gm = torch.gather(m, 1, good[..., None].expand(B, n1, 4)).contiguous()
-    gc = torch.gather(c, 1, good)
+    thr = model.sample_thresh if "threshold" in model.sample_mode else None
+    if sampler == "hip":
+        # the certainty threshold (network.py:391-393) is applied on the fly by the draw and by the gather
+        good = ops.sample_without_replacement(c, n1, one_above=thr)                  # (B,n1)
+        gm, gc = ops.gather_matches(m, c, good, one_above=thr)
+    else:
+        if thr is not None:
+            c = ops.threshold_certainty(c, thr)
+        good = torch.multinomial(c, num_samples=n1, replacement=False)
+        gm = torch.gather(m, 1, good[..., None].expand(B, n1, 4)).contiguous()
+        gc = torch.gather(c, 1, good)
     if "balanced" not in model.sample_mode:
         return gm, gc
     density = ops.kde_density(gm, std=0.1, round_fp16=True)                          # half inputs, fp32 sums
     p = ops.balance_weights(density, round_fp16=True)
     n2 = min(num, n1)
-    bal = draw(p, n2)
+    if sampler == "hip":
+        return ops.gather_matches(gm, gc, ops.sample_without_replacement(p, n2))
+    bal = torch.multinomial(p, num_samples=n2, replacement=False)
     return torch.gather(gm, 1, bal[..., None].expand(B, n2, 4)).contiguous(), torch.gather(gc, 1, bal)
 
 

@@ -302,10 +302,27 @@ def balance_weights(density, min_density=10.0, floor_p=1e-7, round_fp16=False):
     return p
 
 
-def sample_without_replacement(weights, num_samples, seed=None):
+def gather_matches(matches, certainty, idx, one_above=None):
+    """(matches[b, idx[b]], certainty[b, idx[b]]) for a batch (model/network.py:403-404, 414) in one launch; one_above:
+    certainties above it come back as 1 (the threshold of network.py:391-393 applied on the fly)."""
+    dev = require_gpu(matches, certainty, idx)
+    m, c = f32c(matches), f32c(certainty)
+    Bt, N, four = m.shape
+    K = idx.shape[1]
+    if four != 4 or tuple(c.shape) != (Bt, N) or idx.shape[0] != Bt or idx.dtype != torch.int64:
+        raise ValueError("gather_matches: matches (Bt,N,4), certainty (Bt,N), idx (Bt,K) int64")
+    idx = idx.contiguous()
+    om = torch.empty((Bt, K, 4), device=dev, dtype=torch.float32)
+    oc = torch.empty((Bt, K), device=dev, dtype=torch.float32)
+    check(_L().gfn_gather_matches(ptr(m), ptr(c), ptr(idx), ptr(om), ptr(oc), Bt, N, K,
+                                  float("inf") if one_above is None else float(one_above), stream_ptr(dev)), "gfn_gather_matches")
+    return om, oc
+
+
+def sample_without_replacement(weights, num_samples, seed=None, one_above=None):
     """torch.multinomial(weights, num_samples, replacement=False) for a (Bt,N) batch (model/network.py:400-402, 411-413):
     exponential race, one HIP launch pair; indices come back in increasing order.  seed=None draws one from torch's
-    default CPU generator, so torch.manual_seed() makes runs repeatable."""
+    default CPU generator, so torch.manual_seed() makes runs repeatable.  one_above: weights above it count as 1."""
     dev = require_gpu(weights)
     w = f32c(weights)
     if w.dim() != 2:
@@ -316,7 +333,8 @@ def sample_without_replacement(weights, num_samples, seed=None):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     out = torch.empty((Bt, K), device=dev, dtype=torch.int64)
     scratch = torch.empty((Bt * (N + 2048),), device=dev, dtype=torch.int32)
-    check(_L().gfn_sample_without_replacement(ptr(w), N, ptr(out), ptr(scratch), Bt, N, K, int(seed) & (2 ** 64 - 1), stream_ptr(dev)),
+    check(_L().gfn_sample_without_replacement(ptr(w), N, ptr(out), ptr(scratch), Bt, N, K, int(seed) & (2 ** 64 - 1),
+                                              float("inf") if one_above is None else float(one_above), stream_ptr(dev)),
           "gfn_sample_without_replacement")
     return out
 

@@ -202,9 +202,16 @@ int gfn_balance_weights(const float *density, float *p, int64_t n, float min_den
  * GFNet.sample (model/network.py:400-402, 411-413).  Exponential race like torch's implementation (key = w / Exp(1),
  * the num_samples largest keys win) with a counter-based generator: same distribution, its own random stream, the same
  * result for the same seed.  weights (Bt,N) with row stride row_stride (non-negative; zero-weight entries are drawn only
- * when fewer than K positive ones exist), out (Bt,K) int64 indices in increasing order, scratch: Bt*(N + 2048) ints. */
+ * when fewer than K positive ones exist), out (Bt,K) int64 indices in increasing order, scratch: Bt*(N + 2048) ints.
+ * one_above: weights above it count as 1 -- the certainty threshold of model/network.py:391-393 applied on the fly
+ * (+INFINITY: off). */
 int gfn_sample_without_replacement(const float *weights, int64_t row_stride, int64_t *out, int *scratch, int Bt, int N, int K,
-                                   uint64_t seed, gfn_stream_t stream);
+                                   uint64_t seed, float one_above, gfn_stream_t stream);
+/* The gathers that follow a draw (model/network.py:403-404, 414): out_matches[b][i] = matches[b][idx[b][i]] (rows of four
+ * floats, 16-byte aligned), out_certainty[b][i] = certainty[b][idx[b][i]], thresholded like above.  matches (Bt,N,4),
+ * certainty (Bt,N), idx (Bt,K) int64. */
+int gfn_gather_matches(const float *matches, const float *certainty, const int64_t *idx, float *out_matches, float *out_certainty,
+                       int Bt, int N, int K, float one_above, gfn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Homography solve -- estimation.py:60-77 (cv2.findHomography(..., cv2.RANSAC, confidence=0.99999,

@@ -430,6 +430,25 @@ def test_sample_without_replacement_is_a_valid_draw(N):
     np.testing.assert_array_equal(host(ops.sample_without_replacement(dev(w2), 1000, seed=1))[0], np.arange(1000))
 
 
+def test_gather_matches_and_on_the_fly_threshold():
+    from gfnet_amd import ops
+
+    rng = np.random.default_rng(11)
+    Bt, N, K = 3, 5000, 700
+    m = dev(rng.standard_normal((Bt, N, 4)).astype(np.float32))
+    c = dev(rng.uniform(0, 0.2, size=(Bt, N)).astype(np.float32))
+    idx = torch.stack([torch.randperm(N, device="cuda")[:K] for _ in range(Bt)])
+    om, oc = ops.gather_matches(m, c, idx)
+    assert torch.equal(om, torch.gather(m, 1, idx[..., None].expand(Bt, K, 4)))
+    assert torch.equal(oc, torch.gather(c, 1, idx))
+    ct = ops.threshold_certainty(c, 0.05)                       # network.py:391-393 as a separate pass ...
+    om2, oc2 = ops.gather_matches(m, c, idx, one_above=0.05)    # ... and applied by the gather
+    assert torch.equal(om2, om) and torch.equal(oc2, torch.gather(ct, 1, idx))
+    a = ops.sample_without_replacement(ct, 900, seed=5)         # the draw sees the same weights either way
+    b = ops.sample_without_replacement(c, 900, seed=5, one_above=0.05)
+    assert torch.equal(a, b)
+
+
 def test_sample_without_replacement_follows_the_weights():
     """First-draw law: with K = 1 the index is drawn with probability w_i / sum(w); inclusion frequencies of a K-subset
     must match torch.multinomial's (same exponential-race law) within sampling noise."""
