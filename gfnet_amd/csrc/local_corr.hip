@@ -467,7 +467,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     Region u;
     u.x0 = bbox[0]; u.y0 = bbox[1];
     u.w = max(bbox[2] - u.x0, 0); u.h = max(bbox[3] - u.y0, 0);
-    u.pitch = u.w + ((PW - u.w) & 15);
+    u.pitch = u.w + ((PW - u.w) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
+    // a region that only fits without that padding is staged unpadded: some bank conflicts in the D-stage cost far less
+    // than the second launch
+    if (STAGED && (long)u.pitch * u.h > kCapSlots && (long)u.w * u.h <= kCapSlots) u.pitch = u.w;
     if (STAGED && (long)u.pitch * u.h > kCapSlots) {
         // strong magnification / rotation / scattered flow: the windows do not fit the stage
         if (!SECOND) {
