@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void kde4_operands_kernel(const float *__restr
 // adds the two halves.  The diagonal block p == q holds both (i,j) and (j,i) and feeds row sums only.
 constexpr float kKdeFixScale = 1099511627776.f;  // 2^40
 template <bool SYM>
-__global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__restrict__ xs, const bf16x8 *__restrict__ aop,
+__global__ __launch_bounds__(kKdeThreads, 4) void kde4_mfma_kernel(const float *__restrict__ xs, const bf16x8 *__restrict__ aop,
                                                                 const bf16x8 *__restrict__ bop, const float *__restrict__ box,
                                                                 float *__restrict__ part, unsigned long long *__restrict__ colacc,
                                                                 int N, int Mp, int NT, int MT, int tile_cull) {
@@ -498,55 +498,40 @@ __global__ __launch_bounds__(kKdeThreads) void kde4_mfma_kernel(const float *__r
             }
             const int bit = cur - base;
             const bool s00 = (m00 >> bit) & 1, s01 = (m01 >> bit) & 1, s10 = (m10 >> bit) & 1, s11 = (m11 >> bit) & 1;  // scalar
-            f32x16 e0 = zero16, e1 = zero16, f0 = zero16, f1 = zero16;
-            if (s00) {
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c0, zero16, 0, 0, 0);
-                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c1, e0, 0, 0, 0);
-            }
-            if (s10) {
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c0, zero16, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c1, e1, 0, 0, 0);
-            }
-            if (s01) {
-                f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, c2, zero16, 0, 0, 0);
-                f0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, c3, f0, 0, 0, 0);
-            }
-            if (s11) {
-                f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, c2, zero16, 0, 0, 0);
-                f1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, c3, f1, 0, 0, 0);
-            }
+            // column tile 0 then column tile 1, each: MFMAs, then its exponentials -- the products of the two tiles share
+            // registers (4 waves per SIMD instead of 3); other waves' exponentials run under this wave's MFMAs
             f32x2 cs0 = f32x2{0.f, 0.f}, cs1 = f32x2{0.f, 0.f};  // SYM: this lane's column of the two column tiles
-            if (s00) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
-                    acc0[r] += x;
-                    if (SYM) cs0 += x;
+            for (int ct = 0; ct < 2; ++ct) {
+                const bool sa = ct ? s01 : s00, sb = ct ? s11 : s10;
+                const bf16x8 ca = ct ? c2 : c0, cb = ct ? c3 : c1;
+                f32x16 e0 = zero16, e1 = zero16;
+                if (sa) {
+                    e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, ca, zero16, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, cb, e0, 0, 0, 0);
                 }
-            }
-            if (s10) {
+                if (sb) {
+                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, ca, zero16, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, cb, e1, 0, 0, 0);
+                }
+                f32x2 cs = f32x2{0.f, 0.f};
+                if (sa) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
-                    acc1[r] += x;
-                    if (SYM) cs0 += x;
+                    for (int r = 0; r < 8; ++r) {
+                        const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e0[2 * r]), __builtin_amdgcn_exp2f(-e0[2 * r + 1])};
+                        acc0[r] += x;
+                        if (SYM) cs += x;
+                    }
                 }
-            }
-            if (s01) {
+                if (sb) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-f0[2 * r]), __builtin_amdgcn_exp2f(-f0[2 * r + 1])};
-                    acc0[r] += x;
-                    if (SYM) cs1 += x;
+                    for (int r = 0; r < 8; ++r) {
+                        const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-e1[2 * r]), __builtin_amdgcn_exp2f(-e1[2 * r + 1])};
+                        acc1[r] += x;
+                        if (SYM) cs += x;
+                    }
                 }
-            }
-            if (s11) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const f32x2 x = f32x2{__builtin_amdgcn_exp2f(-f1[2 * r]), __builtin_amdgcn_exp2f(-f1[2 * r + 1])};
-                    acc1[r] += x;
-                    if (SYM) cs1 += x;
-                }
+                if (ct) cs1 = cs; else cs0 = cs;
             }
             if (SYM && cur != qblk) {  // wave-uniform
                 // rows 4kh.. of both row tiles are in this lane, the other half of the rows in lane ^ 32
