@@ -488,7 +488,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     const float *f1b = f1_of(p, b);
     constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
     StageRegs<PRE> pre;
-    if (STAGED && !ABL(p, 1)) stage_issue(pre, f1b, H, W, u, wave, lane, 0);
+    constexpr int PRE0 = 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at once
+    StageRegs<PRE0> pre0;
+    if (STAGED && !ABL(p, 1)) stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
 
     // ---- per-lane D-stage addressing -----------------------------------------------------------
     int g, s16;
@@ -530,8 +532,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
     if (STAGED && !ABL(p, 1)) {
-        stage_commit(s4, pre);
-        stage_rest<2>(s4, f1b, H, W, u, wave, lane, PRE);
+        stage_commit(s4, pre0);
+        stage_rest<2>(s4, f1b, H, W, u, wave, lane, PRE0);
     }
     if (STAGED) __syncthreads();
     STAMP(4);
