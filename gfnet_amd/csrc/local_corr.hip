@@ -343,7 +343,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     constexpr int NC = 32 * ROUNDS;          // cells per tile
     constexpr int DS = P + 1;                // D-buffer cell stride (odd: conflict-free epilogue reads)
     constexpr int TS = 2 * D + 1;            // fraction-table cell stride (odd)
-    static_assert((NC * DS + NC * TS) * 4 <= kStageBytes, "D buffer + fraction table must fit in the stage they alias");
+    // small windows (r <= 2, 16-channel maps) leave LDS for a fraction table of its own next to the stage: it is then filled
+    // under the first chunk's stage loads instead of after the D-stage (9 % of the r = 2 kernel)
+    constexpr bool kEarlyTab = R <= 2;
+    static_assert((NC * DS + (kEarlyTab ? 0 : NC * TS)) * 4 <= kStageBytes, "D buffer (+ fraction table) must fit in the stage they alias");
 
     float4 *s4 = reinterpret_cast<float4 *>(smem);
     float *dbuf = reinterpret_cast<float *>(smem);
@@ -355,9 +358,11 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     int *bbox = cellSlow + NC;                                // x0,y0,x1,y1 of the tile's windows
     int *nSlow = bbox + 4;                                    // number of flagged cells in the tile
     int *allInside = bbox + 5;                                // 1 = no window of the tile touches the image border
-    float *tab = dbuf + NC * DS;                              // [NC][TS] per-tap fractions (aliases the stage)
     constexpr int kCellBytes = (NC * 20 + 32 + 15) & ~15;
-    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);  // [NC][C+4]: the tile's f0, cell-major
+    constexpr int kTabBytes = kEarlyTab ? (NC * TS * 4 + 15) & ~15 : 0;
+    float *tab = kEarlyTab ? reinterpret_cast<float *>(smem + kStageBytes + kCellBytes)  // [NC][TS] per-tap fractions
+                           : dbuf + NC * DS;                                               // ... or aliasing the stage
+    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + kTabBytes);  // [NC][C+4]: the tile's f0, cell-major
     const int CS = p.C + 4;                                   // +4: the 4 cells a wave reads hit different banks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,6 +496,28 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     constexpr int PRE0 = 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at once
     StageRegs<PRE0> pre0;
     if (STAGED && !ABL(p, 1)) stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
+
+    // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
+    // (local_correlation.py:55 adds window offsets in normalised units, grid_sample un-normalises)
+    auto fill_table = [&]() {
+        for (int e = tid; e < NC * 2 * D && !ABL(p, 32); e += kThreads) {
+            const int cell = e / (2 * D), a = e - cell * (2 * D);
+            const bool isy = a >= D;
+            const int k = isy ? a - D : a;
+            const float n = isy ? cellNy[cell] : cellNx[cell];
+            const float pix = unnorm(n + (isy ? gfn::linspace_at(ylo, yhi, D, k) : gfn::linspace_at(xlo, xhi, D, k)),
+                                     isy ? H : W);
+            const float fl = floorf(pix);
+            const int origin = isy ? cellY0[cell] : cellX0[cell];
+            // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
+            if (origin != kFar && !(fl == (float)(origin + k))) {
+                cellSlow[cell] = 1;
+                atomicAdd(nSlow, 1);
+            }
+            tab[cell * TS + a] = pix - fl;
+        }
+    };
+    if (kEarlyTab) fill_table();
 
     // ---- per-lane D-stage addressing -----------------------------------------------------------
     int g, s16;
@@ -638,24 +665,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             if (pp < P) dbuf[cell * DS + pp] = acc[rd][t];
         }
     }
-    // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
-    // (local_correlation.py:55 adds window offsets in normalised units, grid_sample un-normalises)
-    for (int e = tid; e < NC * 2 * D && !ABL(p, 32); e += kThreads) {
-        const int cell = e / (2 * D), a = e - cell * (2 * D);
-        const bool isy = a >= D;
-        const int k = isy ? a - D : a;
-        const float n = isy ? cellNy[cell] : cellNx[cell];
-        const float pix = unnorm(n + (isy ? gfn::linspace_at(ylo, yhi, D, k) : gfn::linspace_at(xlo, xhi, D, k)),
-                                 isy ? H : W);
-        const float fl = floorf(pix);
-        const int origin = isy ? cellY0[cell] : cellX0[cell];
-        // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
-        if (origin != kFar && !(fl == (float)(origin + k))) {
-            cellSlow[cell] = 1;
-            atomicAdd(nSlow, 1);
-        }
-        tab[cell * TS + a] = pix - fl;
-    }
+    if (!kEarlyTab) fill_table();
     __syncthreads();
     STAMP(9);
     {
@@ -792,7 +802,8 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     p.r = R; p.win_h = p.H; p.win_w = p.W; p.grid_based = 0;  // what tap_general needs for flagged cells
     p.win_xhi = (float)(2.0 * R / p.W);
     p.win_yhi = (float)(2.0 * R / p.H);
-    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
+    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
+                       (size_t)NC * (p.C + 4) * 4;
     // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
     // one workgroup per CU; absurdly wide features go to the general kernel
     if (lds > kMaxLds) return -1000;
