@@ -31,6 +31,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned n) {
     return start + local;
 }
 
+// The same with the step (end - start) / (steps - 1) supplied by the caller (computed once on the host in fp32: an IEEE
+// division there and here give the same bits; on the device it costs a dozen vector instructions per call).
+__device__ __forceinline__ float linspace_step_at(float start, float end, float step, int steps, int i) {
+    if (steps == 1) return start;
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
 // torch.linspace(start, end, steps)[i] in fp32, the way ATen fills it (from both ends).
 __device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
     if (steps == 1) return start;

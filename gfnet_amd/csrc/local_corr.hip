@@ -61,6 +61,7 @@ struct LcParams {
     float sqrt_c, inv_sqrt_c;
     int r, win_h, win_w, grid_based;  // general path / flagged cells
     float win_xhi, win_yhi;           // tiled path: linspace end points 2r/W, 2r/H rounded to fp32
+    float win_xstep, win_ystep;       // ... and the linspace steps (hi - lo) / (2r), fp32 division done on the host
     int *todo;                        // [4 + B*tiles]: count, queue head of the second launch, its finished workgroups, last call's count, then ids of
                                       // the tiles left to it; all three counters are zero between calls (the second launch resets them)
     long todo_ints;
@@ -281,7 +282,7 @@ __device__ __forceinline__ void stage_issue(StageRegs<N> &r, const float *f1c, i
                                             int lane, int wi_begin) {
     const int npx = rg.w * rg.h;
     const int nwi = ((npx + 63) >> 6) * 4;
-    const float inv_w = 1.0f / (float)rg.w;
+    const float inv_w = __builtin_amdgcn_rcpf((float)rg.w);  // 1 ulp is plenty: (q + 0.5) / w stays >= 0.5 / w away from an integer
     const unsigned pl32 = (unsigned)(H * W);
 #pragma unroll
     for (int u = 0; u < N; ++u) {
@@ -420,8 +421,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             nx = pre_nx; ny = pre_ny;
             // patch origin = floor of the reference's own fp32 coordinate of tap 0:
             // taps kx=0..2R then read columns kx and kx+1 of the patch
-            const float fx = floorf(unnorm(nx + gfn::linspace_at(xlo, xhi, D, 0), W));
-            const float fy = floorf(unnorm(ny + gfn::linspace_at(ylo, yhi, D, 0), H));
+            const float fx = floorf(unnorm(nx + xlo, W));  // linspace(lo, hi, D)[0] == lo
+            const float fy = floorf(unnorm(ny + ylo, H));
             if ((fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f)) {  // false for nan/inf
                 X0 = (int)fx;
                 Y0 = (int)fy;
@@ -505,7 +506,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             const bool isy = a >= D;
             const int k = isy ? a - D : a;
             const float n = isy ? cellNy[cell] : cellNx[cell];
-            const float pix = unnorm(n + (isy ? gfn::linspace_at(ylo, yhi, D, k) : gfn::linspace_at(xlo, xhi, D, k)),
+            const float pix = unnorm(n + (isy ? gfn::linspace_step_at(ylo, yhi, p.win_ystep, D, k) : gfn::linspace_step_at(xlo, xhi, p.win_xstep, D, k)),
                                      isy ? H : W);
             const float fl = floorf(pix);
             const int origin = isy ? cellY0[cell] : cellX0[cell];
@@ -802,6 +803,11 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     p.r = R; p.win_h = p.H; p.win_w = p.W; p.grid_based = 0;  // what tap_general needs for flagged cells
     p.win_xhi = (float)(2.0 * R / p.W);
     p.win_yhi = (float)(2.0 * R / p.H);
+    {   // exactly the fp32 operations linspace_at performs: (end - start) / (float)(steps - 1)
+        const volatile float xlo = -p.win_xhi, ylo = -p.win_yhi, n1 = (float)(2 * R);
+        p.win_xstep = (p.win_xhi - xlo) / n1;
+        p.win_ystep = (p.win_yhi - ylo) / n1;
+    }
     const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
                        (size_t)NC * (p.C + 4) * 4;
     // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
