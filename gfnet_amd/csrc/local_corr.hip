@@ -494,7 +494,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     const float *f1b = f1_of(p, b);
     constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
     StageRegs<PRE> pre;
-    constexpr int PRE0 = 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at once
+    constexpr int PRE0 = R <= 2 ? 4 : 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at
+                                          // once (r <= 2 regions need 3.5 iterations; unused ones still cost their index math)
     StageRegs<PRE0> pre0;
     if (STAGED && !ABL(p, 1)) stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
 
