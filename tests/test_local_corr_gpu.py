@@ -87,7 +87,7 @@ SHAPES = [(64, 32, 32, 7), (64, 56, 32, 6), (32, 112, 64, 4), (16, 224, 128, 2),
 
 
 @pytest.mark.parametrize("c,hs,G,r", SHAPES)
-@pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random"])
+@pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random", "zoom1.2", "zoom1.35"])
 def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
     B = 2
     f0 = synth.lattice_normalish((B, c, G, G), 31 + r)
@@ -96,6 +96,8 @@ def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
         flow = synth.homography_flow(B, G, 33)
     elif flow_kind == "zoom":  # magnified + partly outside: tiles fall back to per-round staging / per-tap
         flow = synth.homography_flow(B, G, 34, scale=1.7)
+    elif flow_kind.startswith("zoom"):  # mild magnification: regions that fit the stage only without its pitch padding
+        flow = synth.homography_flow(B, G, 36, scale=float(flow_kind[4:]))
     else:  # uncorrelated flow: no two neighbouring cells share a window
         flow = 1.2 * synth.lattice_uniform((B, 2, G, G), 35)
     out = run(f0, f1, flow, r, G)
