@@ -47,6 +47,9 @@ static_assert((kCapSlots + 1) * kSlotV4 < 65536, "stage indices are packed in 16
 constexpr int kTileW = 16;
 constexpr int kMaxLds = 150 * 1024;       // dynamic LDS a tiled launch may ask for
 constexpr int kFar = 1 << 28;             // patch origin of a cell that samples nothing
+constexpr int kTodoHdr = 8;               // ints in front of the tile list in scratch: [0] tiles left to the second launch, [1] its queue head,
+                                          // [2] its finished workgroups, [3] last call's [0], [4] cells redone per tap (running call),
+                                          // [5] last call's [4], [6..7] spare; [0..2] and [4] are zero between calls
 
 struct LcParams {
     const float *f0;
@@ -62,9 +65,9 @@ struct LcParams {
     int r, win_h, win_w, grid_based;  // general path / flagged cells
     float win_xhi, win_yhi;           // tiled path: linspace end points 2r/W, 2r/H rounded to fp32
     float win_xstep, win_ystep;       // ... and the linspace steps (hi - lo) / (2r), fp32 division done on the host
-    int *todo;                        // [4 + B*tiles]: count, queue head of the second launch, its finished workgroups, last call's count, then ids of
-                                      // the tiles left to it; all three counters are zero between calls (the second launch resets them)
+    int *todo;                        // [kTodoHdr + B*tiles]: header (see kTodoHdr), then the ids of the tiles left to the second launch
     long todo_ints;
+    int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
 #endif
@@ -480,7 +483,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     if (STAGED && (long)u.pitch * u.h > kCapSlots) {
         // strong magnification / rotation / scattered flow: the windows do not fit the stage
         if (!SECOND) {
-            if (tid == 0) p.todo[4 + atomicAdd(p.todo, 1)] = (int)wid;
+            if (tid == 0) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;
         } else {
             __syncthreads();
             if (ABL(p, 1024)) return;
@@ -770,33 +773,60 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
     constexpr int SUBS = (TH / SH) * (kTileW / 8);
     const int n = p.todo[0] * SUBS;
     const int tiles = p.tiles_x * p.tiles_y;
-    // work items differ by 10x (a staged sub-tile vs one that gathers from L2): hand them out first come, first served
+    // Only as many workgroups as there are work items take part (the rest leave at once): with no tile on the list -- the
+    // common case -- the launch costs one load per workgroup instead of two contended atomics (14 us for 512 workgroups).
+    const int part = n < (int)gridDim.x ? n : (int)gridDim.x;
+    if ((int)blockIdx.x >= (part > 0 ? part : 1)) return;
+    // work items differ by 10x (a staged sub-tile vs one that gathers from L2): after its first item (its own block id) a
+    // workgroup draws tickets first come, first served
     __shared__ int next_item;
-    while (true) {
-        if (threadIdx.x == 0) next_item = atomicAdd(p.todo + 1, 1);
-        __syncthreads();
-        const int it = __builtin_amdgcn_readfirstlane(next_item);  // scalar: everything derived from it (b, map bases) stays in SGPRs
-        if (it >= n) break;
-        const unsigned wid = (unsigned)p.todo[4 + it / SUBS];
+    int it = (int)blockIdx.x;
+    while (it < n) {
+        const unsigned wid = (unsigned)p.todo[kTodoHdr + it / SUBS];
         const int sub = it % SUBS;
         const int b = wid / tiles, tile = wid - b * tiles;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         process_tile<R, 1, true, 8, true>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
         __syncthreads();  // LDS (and next_item) are reused by the next sub-tile
+        if (threadIdx.x == 0) next_item = part + atomicAdd(p.todo + 1, 1);
+        __syncthreads();
+        it = __builtin_amdgcn_readfirstlane(next_item);  // scalar: everything derived from it (b, map bases) stays in SGPRs
     }
-    // the last workgroup to leave puts the three counters back to zero for the next call: no memset node in front of
-    // every call (4.7 us each, 3 % of the scale-4 op).  Every workgroup has read todo[0] and drawn its last queue ticket
-    // before it gets here.
-    if (threadIdx.x == 0 && atomicAdd(p.todo + 2, 1) == (int)gridDim.x - 1) {
-        p.todo[3] = p.todo[0];  // informational (tools/count_irregular.py)
+    // the last workgroup to leave puts the counters back to zero for the next call: no memset node in front of every call.
+    // Every participant has read todo[0] and drawn its last queue ticket before it gets here.
+    if (threadIdx.x == 0 && (part <= 1 || atomicAdd(p.todo + 2, 1) == part - 1)) {
+        p.todo[3] = p.todo[0];  // informational (tools/count_irregular.py, bench.py)
+        p.todo[5] = p.todo[4];
+        p.todo[4] = 0;
         p.todo[0] = 0;
         p.todo[1] = 0;
         p.todo[2] = 0;
     }
 }
 
+#include "local_corr_lean.h"
+
+template <int R, int NCH>
+void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH>), dim3(total), dim3(kThreads), lds, stream, p);
+}
+
+// compute units of the current device (queried once per device: hipGetDeviceProperties is slow)
+int device_cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
 template <int R, int ROUNDS>
-int launch_tile(const LcParams &p0, hipStream_t stream) {
+int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
@@ -814,19 +844,31 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
     // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
     // one workgroup per CU; absurdly wide features go to the general kernel
     if (lds > kMaxLds) return -1000;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        attr_set = true;
-    }
+    // per call and unconditional: the attribute is per device, a process may drive several
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
-    if ((size_t)p.todo_ints < (size_t)total + 4) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(total), dim3(kThreads), lds, stream, p);
-    if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
-    const unsigned grid2 = total < 512 ? total : 512;
+    if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
+    if constexpr (ROUNDS == 2) {
+        if (lean) {
+            const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
+            hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
+            if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
+            switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
+                case 16: launch_lean<R, 1>(p, total, lds2, stream); break;
+                case 32: launch_lean<R, 2>(p, total, lds2, stream); break;
+                default: launch_lean<R, 4>(p, total, lds2, stream); break;
+            }
+            if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
+        }
+    }
+    if (!(lean && ROUNDS == 2)) {
+        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(total), dim3(kThreads), lds, stream, p);
+        if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
+    }
+    const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
     hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS>), dim3(grid2), dim3(kThreads), lds, stream, p);
     return gfn::check_launch("local_corr_irregular_kernel");
 }
@@ -837,7 +879,8 @@ int launch_tile(const LcParams &p0, hipStream_t stream) {
 GFN_EXPORT int64_t gfn_local_corr_scratch_bytes(int B, int G) {
     // smallest tile is 2 x 16 cells -> at most B * ceil(G/2) * ceil(G/16) tiles, plus the counter
     const int64_t tiles = (int64_t)((G + 1) / 2) * ((G + 15) / 16);
-    return 4 * ((int64_t)B * tiles + 4);
+    // header + tile list (ints), then the lean path's plan (16 bytes per tile, 16-byte aligned)
+    return 4 * ((int64_t)B * tiles + kTodoHdr) + 16 + 16 * (int64_t)B * tiles;
 }
 
 GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second,
@@ -870,24 +913,35 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     p.r = r; p.win_h = win_h; p.win_w = win_w; p.grid_based = grid_based;
     p.todo = reinterpret_cast<int *>(scratch);
     p.todo_ints = scratch ? scratch_bytes / 4 : 0;
+    p.plan = nullptr;
 #ifdef GFN_ABLATE
     p.dbg = variant >> 8;
     variant &= 0xff;
 #endif
 
     // the tiled path needs the tile list in scratch; without it the general kernel still gives the right answer
-    const bool fast_ok = variant == 0 && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7 &&
+    // variant 0: the tiled path (lean tile kernel for r <= 4); 1: general kernel; 2: the round-1 tile kernel for every radius
+    // (kept as the bit-exact cross-check of the lean kernel)
+    // the lean path keeps at most 8 channels of the f0 block per wave in registers and addresses planes with 32-bit byte offsets
+    bool lean = variant == 0 && flow && (C == 16 || C == 32 || C == 64) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
+    if (lean && scratch) {
+        const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
+        const uintptr_t pl = ((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 15) & ~(uintptr_t)15;
+        p.plan = reinterpret_cast<int *>(pl);
+        p.todo_ints = tiles_max + kTodoHdr;
+    }
+    const bool fast_ok = (variant == 0 || variant == 2) && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7 &&
                          scratch && scratch_bytes >= gfn_local_corr_scratch_bytes(B, G) && ((uintptr_t)scratch & 3) == 0;
     if (fast_ok) {
         int rc = -1000;
         switch (r) {
-            case 1: rc = launch_tile<1, 2>(p, s); break;
-            case 2: rc = launch_tile<2, 2>(p, s); break;
-            case 3: rc = launch_tile<3, 2>(p, s); break;
-            case 4: rc = launch_tile<4, 2>(p, s); break;
-            case 5: rc = launch_tile<5, 1>(p, s); break;
-            case 6: rc = launch_tile<6, 1>(p, s); break;
-            case 7: rc = launch_tile<7, 1>(p, s); break;
+            case 1: rc = launch_tile<1, 2>(p, s, lean); break;
+            case 2: rc = launch_tile<2, 2>(p, s, lean); break;
+            case 3: rc = launch_tile<3, 2>(p, s, lean); break;
+            case 4: rc = launch_tile<4, 2>(p, s, lean); break;
+            case 5: rc = launch_tile<5, 1>(p, s, lean); break;
+            case 6: rc = launch_tile<6, 1>(p, s, lean); break;
+            case 7: rc = launch_tile<7, 1>(p, s, lean); break;
         }
         if (rc != -1000) return rc;  // -1000: shape not supported by the tiled path
     }

@@ -1,0 +1,573 @@
+// local_corr_lean.h -- the round-2 tile path of the local correlation (r <= 4).  Included by local_corr.hip inside its
+// anonymous namespace (shares LcParams, cell_coords, tap_general, lane_group, wave_min_i32, unnorm, f1_of).
+//
+// Same tile (4 x 16 cells), LDS slot layout, D-stage and arithmetic as process_tile<R, 2, true, 16, false>: results are
+// bit-identical to the round-1 kernel (tests/test_local_corr_gpu.py).  What changed is everything around the D-stage.
+// Round-1 evidence (profiles/local_corr_sq_pmc.json, s_memtime stamps in profiles/r02_local_corr_stamps.md): a tile lived
+// ~33 k cycles of which the D-stage proper is 2 x 2.8 k; the rest were two serialised memory round trips in the set-up
+// (flow -> bounding box -> barrier -> stage loads), the *issue* of ~550 narrow vector loads per tile (38 of 64 lanes
+// active, ~13 cycles each through the address path), and 1397 vector instructions per wave for 448 FMAs, many of them
+// quarter-rate integer multiplies and 64-bit address adds.
+//   * plan launch: one wave per tile reads the flow, builds the tile's staging region and writes it to scratch (and the ids
+//     of the tiles whose windows do not fit the stage straight to the second launch's list).  The tile kernel therefore
+//     issues the plan load, its flow loads and the f0 block at entry, the stage loads as soon as the 16-byte plan is back:
+//     one memory round trip and ONE barrier in front of the D-stage instead of two of each;
+//   * staging loads are 16-byte quads along the image row (a work item = 64 / quads-per-row region rows x 4 channel planes:
+//     four loads bring 4 pixels x 4 channels per lane, written as four 16-byte LDS slots): ~5x fewer vector-memory
+//     instructions, every lane busy; the region starts on a multiple of 4 pixels so that the quads are 16-byte aligned;
+//   * all global traffic goes through buffer instructions: descriptor (SGPRs) + scalar offset per plane / row group +
+//     a per-lane offset that is constant for the tile -- no vector address arithmetic at all;
+//   * the region is the UNclipped bounding box of the windows that touch the image, out-of-image pixels are staged as
+//     zeros (border tiles only, a block-uniform variant), so the D-stage addresses need no per-position tests and no zero
+//     slot; cells whose window misses the image entirely never enter the box and get exact zeros from the epilogue;
+//   * tile = two 4 x 8-cell halves (cells 0-31 / 32-63), the epilogue still stores 64-byte row segments;
+//   * fraction table: lane = cell, wave = tap index (no division); stores use scalar plane offsets.
+
+constexpr int kPlanInts = 4;  // per tile: region x0 (multiple of 4 when W is), y0, (h << 16) | w, flags
+constexpr int kPlanInterior = 1, kPlanSecond = 2;
+
+// cell id inside a tile -> (row, column): cells 0-31 are the left 4 x 8 half, 32-63 the right one
+__device__ __forceinline__ int cell_row(int c) { return (c & 31) >> 3; }
+__device__ __forceinline__ int cell_col(int c) { return (c & 7) + ((c >> 5) << 3); }
+
+// stage bytes of the lean kernel: small windows (r <= 2: 6 x 6 patches over 16-channel maps) need half the region, and with
+// 40 KB three workgroups fit a CU
+template <int R>
+struct Lean {
+    static constexpr int kStage = R <= 2 ? 40 * 1024 : 64 * 1024;  // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU
+    static constexpr int kCap = kStage / (kSlotV4 * 16);
+    static constexpr int kMinWaves = R <= 2 ? 6 : 4;  // waves per SIMD the register allocation must allow
+    static constexpr int PW = 2 * R + 2;
+};
+
+// what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
+struct CellBox {
+    int X0, Y0, flag;
+    int bx0, by0, bx1, by1;
+    bool inside;
+};
+constexpr int kCellSlow = 1, kCellEmpty = 2;
+
+template <int PW>
+__device__ __forceinline__ CellBox cell_box(bool ok, float nx, float ny, float xlo, float ylo, int W, int H) {
+    CellBox c;
+    c.X0 = kFar; c.Y0 = kFar; c.flag = 0;
+    c.bx0 = kFar; c.by0 = kFar; c.bx1 = -kFar; c.by1 = -kFar;
+    c.inside = true;
+    if (ok) {
+        // patch origin = floor of the reference's own fp32 coordinate of tap 0 (linspace(lo, hi, D)[0] == lo)
+        const float fx = floorf(unnorm(nx + xlo, W));
+        const float fy = floorf(unnorm(ny + ylo, H));
+        if ((fx > -1e6f) & (fx < 1e6f) & (fy > -1e6f) & (fy < 1e6f)) {  // false for nan/inf
+            const int ix = (int)fx, iy = (int)fy;
+            if ((ix < W) & (ix + PW > 0) & (iy < H) & (iy + PW > 0)) {  // the window touches the image
+                c.X0 = ix; c.Y0 = iy;
+                c.bx0 = ix; c.by0 = iy; c.bx1 = ix + PW; c.by1 = iy + PW;  // unclipped: out-of-image pixels are staged as zeros
+                c.inside = (ix >= 0) & (ix + PW <= W) & (iy >= 0) & (iy + PW <= H);
+            } else {
+                c.flag = kCellEmpty;
+            }
+        } else {
+            c.flag = kCellSlow;  // non-finite / absurd flow: the per-tap routine decides
+        }
+    }
+    return c;
+}
+
+// region geometry from the box, identically in the plan kernel and the tile kernel
+struct RowPlan {  // block-uniform (scalars)
+    int x0, y0, w, h, pitch;
+    int nq;       // 16-byte quads per region row
+    int rpi;      // region rows per work item (<= 64 / nq)
+    int nitems;   // (row group, channel quad) pairs of a 16-channel chunk: a multiple of 8, nitems / 8 per wave
+};
+
+template <int R>
+__device__ __forceinline__ bool region_fits(RowPlan &u) {
+    constexpr int PW = Lean<R>::PW;
+    u.nq = (u.w + 3) >> 2;
+    const int w4 = u.nq * 4;
+    u.pitch = w4 + ((PW - w4) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
+    if ((long)u.pitch * u.h > Lean<R>::kCap && (long)w4 * u.h <= Lean<R>::kCap) u.pitch = w4;
+    if ((long)u.pitch * u.h > Lean<R>::kCap || u.w > 64) return false;
+    // row groups: an even number of them, so that the 4 * groups work items of a chunk split evenly over the 8 waves
+    // (every wave issues the same number of loads: no branches around loads, exact wait counts)
+    const int rpi_max = u.nq > 0 ? 64 / u.nq : 64;
+    int ng = (u.h + rpi_max - 1) / rpi_max;
+    ng = (ng + 1) & ~1;
+    u.rpi = ng > 0 ? (u.h + ng - 1) / ng : 1;
+    u.nitems = ng * 4;
+    return true;
+}
+
+// ---- plan launch: a wave plans kPlanPerWave tiles (all their flow loads in flight together) -----------------------------
+constexpr int kPlanPerWave = 4;
+template <int R>
+__global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
+    constexpr int PW = Lean<R>::PW;
+    const int lane = threadIdx.x & 63;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const unsigned total = (unsigned)(p.B * tiles);
+    const unsigned wid0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kPlanPerWave;
+    float nx[kPlanPerWave], ny[kPlanPerWave];
+    bool ok[kPlanPerWave];
+#pragma unroll
+    for (int t = 0; t < kPlanPerWave; ++t) {
+        const unsigned wid = wid0 + t < total ? wid0 + t : total - 1;
+        const int b = wid / tiles, tile = wid - b * tiles;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int gi = ty * 4 + cell_row(lane), gj = tx * kTileW + cell_col(lane);
+        ok[t] = (gi < p.G) & (gj < p.G);
+        const size_t o = ((size_t)b * 2 * p.G + (ok[t] ? gi : 0)) * p.G + (ok[t] ? gj : 0);
+        nx[t] = p.flow[o];
+        ny[t] = p.flow[o + (size_t)p.G * p.G];
+    }
+#pragma unroll
+    for (int t = 0; t < kPlanPerWave; ++t) {
+        const unsigned wid = wid0 + t;
+        if (wid >= total) break;
+        const CellBox c = cell_box<PW>(ok[t], nx[t], ny[t], -p.win_xhi, -p.win_yhi, p.W, p.H);
+        const int bx0 = wave_min_i32(c.bx0), by0 = wave_min_i32(c.by0);
+        const int bx1 = -wave_min_i32(-c.bx1), by1 = -wave_min_i32(-c.by1);
+        const bool all_in = __all(c.inside);
+        if (lane == 0) {
+            RowPlan u;
+            // 16-byte aligned quads (region starting on a multiple of 4 pixels, rows and planes multiples of 4 too) where that
+            // is free, i.e. does not add a quad per row -- an extra quad pushes the row pitch to the next conflict-free value
+            // (16 slots more) or the region out of the stage.  Border tiles need the alignment (whole-quad masks).
+            u.x0 = bx0;
+            if ((p.W & 3) == 0) {
+                const int xa = bx0 & ~3;
+                if (!all_in || ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2)) u.x0 = xa;
+            }
+            u.y0 = by0;
+            u.w = max(bx1 - u.x0, 0);
+            u.h = max(by1 - by0, 0);
+            if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
+            // border tiles are staged with whole-quad masks, which needs rows that are multiples of 4 pixels: otherwise (no
+            // production shape) the tile goes to the second launch
+            const bool fits = region_fits<R>(u) && (all_in || (p.W & 3) == 0);
+            const int flags = (all_in ? kPlanInterior : 0) | (fits ? 0 : kPlanSecond);
+            int4 pl;
+            pl.x = u.x0; pl.y = u.y0; pl.z = (u.h << 16) | u.w; pl.w = flags;
+            reinterpret_cast<int4 *>(p.plan)[wid] = pl;
+            if (!fits) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;  // strong magnification / scattered flow: second launch
+        }
+    }
+}
+
+// ---- buffer addressing --------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_i32x4(int a, int b, int c, int d) { i32x4 v = {a, b, c, d}; return v; }
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_ld4(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st_nt(rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 2);  // 2 = nt (streaming store)
+}
+
+// ---- staging: 16-byte quads along the row --------------------------------------------------------------------------
+// Work item it (of a 16-channel chunk) = (row group it >> 2, channel quad it & 3); wave w takes items w, w + 8, ...  A lane
+// owns quad `q` of region row `rg * rpi + ry` (ry = lane / nq, q = lane % nq): four loads (one per channel plane of the
+// quad) bring 4 pixels x 4 channels, which leave as four 16-byte slot writes (pixel-major [pixel][16 channels + pad]).
+template <int N>
+struct QuadRegs {
+    f32x4 a[N][4];  // [item][channel of the quad] -> 4 pixels
+};
+
+struct QuadLane {         // per lane, constant for the tile
+    unsigned voff;        // byte offset of the lane's quad inside an image plane, relative to the region's first row group
+    int slot;             // float4 index of the lane's first pixel slot, relative to the row group and channel quad
+    int ry;               // region row inside a row group (>= rpi: lane idle)
+    unsigned xmask;       // CHECK: bit k set = pixel k of the quad lies inside the image
+};
+
+template <int N, bool CHECK>
+__device__ __forceinline__ void quad_issue(QuadRegs<N> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
+                                           const QuadLane &ql, int k0) {
+    const unsigned plane4 = (unsigned)(H * W) * 4u;
+    const int ipw = u.nitems >> 3;  // items per wave
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        // no branch around the loads: an item past the wave's last one repeats it (same addresses: L1 hits, result unused)
+        const int it = wave + 8 * max(min(k0 + n, ipw - 1), 0);   // scalar
+        const int cg = it & 3, row0 = (it >> 2) * u.rpi;          // scalars
+        unsigned so = chunk_off + (unsigned)cg * 4u * plane4, vo;
+        if (!CHECK) {
+            so += (unsigned)((u.y0 + row0) * W) * 4u;             // every staged row lies inside the image
+            vo = ql.voff;
+        } else {
+            // rows may lie outside the image (then the scalar row offset could be negative): the row goes into the
+            // per-lane offset, lanes of outside rows point at pixel 0 and are zeroed at the commit
+            const int gy = u.y0 + row0 + ql.ry;
+            vo = (unsigned)gy < (unsigned)H ? ql.voff + (unsigned)((u.y0 + row0) * W) * 4u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.a[n][j] = buf_ld4(f1r, vo, so + (unsigned)j * plane4);
+    }
+}
+
+template <int N, bool CHECK>
+__device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N> &r, int H, const RowPlan &u, int wave, const QuadLane &ql, int k0) {
+    const int ipw = u.nitems >> 3;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int it = wave + 8 * (k0 + n);
+        const int cg = it & 3, row0 = (it >> 2) * u.rpi;
+        if ((k0 + n < ipw) & (ql.ry < u.rpi) & (row0 + ql.ry < u.h)) {
+            float4 *dst = s4 + (ql.slot + row0 * u.pitch) * kSlotV4 + cg;
+            unsigned m = 0xFu;
+            if (CHECK) m = (unsigned)(u.y0 + row0 + ql.ry) < (unsigned)H ? ql.xmask : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 v = make_float4(r.a[n][0][k], r.a[n][1][k], r.a[n][2][k], r.a[n][3][k]);
+                if (CHECK && !((m >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[k * kSlotV4] = v;
+            }
+        }
+    }
+}
+
+template <bool CHECK>
+__device__ __forceinline__ void quad_rest(float4 *s4, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
+                                          const QuadLane &ql, int done) {
+    for (int k0 = done; k0 < (u.nitems >> 3); ++k0) {  // only regions taller than two row groups per wave pair (rare)
+        QuadRegs<1> r;
+        quad_issue<1, CHECK>(r, f1r, chunk_off, H, W, u, wave, ql, k0);
+        quad_commit<1, CHECK>(s4, r, H, u, wave, ql, k0);
+    }
+}
+
+// pp / PW for pp < 128 by a 24-bit multiply and a shift (the generic 32-bit magic division is a quarter-rate multiply-high)
+template <int PW>
+struct DivPW {
+    static constexpr int S = 12;
+    static constexpr int M = ((1 << S) + PW - 1) / PW;
+    static constexpr bool exact() {
+        for (int v = 0; v < 128; ++v)
+            if (((v * M) >> S) != v / PW) return false;
+        return true;
+    }
+    static_assert(exact(), "mul-shift division must be exact on the patch positions");
+    __device__ static __forceinline__ int div(int v) { return (int)(((unsigned)v * (unsigned)M) >> S); }
+};
+
+// One tile.  CHECK: the region sticks out of the image (border tiles).  Everything that loads from global memory is
+// straight-line code (no branches around loads), so that the compiler's wait counts stay exact: with conditional loads it
+// falls back to vmcnt(0) and the cell set-up ends up waiting for the stage loads issued after it.
+template <int R, int NCH, bool CHECK>
+__device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &u, unsigned wid, int tid, int lane, int wave) {
+    constexpr int ROUNDS = 2;
+    constexpr int C = 16 * NCH;
+    constexpr int kStageBytes = Lean<R>::kStage;  // shadows the round-1 constant
+    constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
+    constexpr int D = 2 * R + 1, K = D * D;
+    constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
+    constexpr int CS = C + 4;
+    static_assert(NC * DS * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
+
+    float4 *s4 = reinterpret_cast<float4 *>(smem);
+    float *dbuf = reinterpret_cast<float *>(smem);
+    int *cellX0 = reinterpret_cast<int *>(smem + kStageBytes);
+    int *cellY0 = cellX0 + NC;
+    float *cellNx = reinterpret_cast<float *>(cellY0 + NC);
+    float *cellNy = cellNx + NC;
+    int *cellFlag = reinterpret_cast<int *>(cellNy + NC);     // kCellSlow: redo per tap; kCellEmpty: window misses the image, result 0
+    int *hdr = cellFlag + NC;                                  // [4]: number of flagged cells
+    constexpr int kCellBytes = (NC * 20 + 32 + 15) & ~15;
+    constexpr int kTabBytes = (NC * TS * 4 + 15) & ~15;
+    float *tab = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);   // [NC][TS] per-tap fractions
+    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + kTabBytes);  // [NC][C + 4]: the tile's f0, cell-major
+
+    const int G = p.G, H = p.H, W = p.W;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int b = wid / tiles, tile = wid - b * tiles;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const int row0 = ty * 4, col0 = tx * kTileW;
+    const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;
+    const unsigned GG4 = (unsigned)(G * G) * 4u;  // bytes of a (G,G) plane
+#ifdef GFN_ABLATE
+    const bool stamping = ABL(p, 512) && (blockIdx.x % 1999) == 1000 && (tid & 63) == 0 && (tid >> 6) < 2;
+    long long stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
+
+    // ---- flow, the f0 block and the first chunk's stage loads all go out at once ------------------------------------------
+    // lane = cell id (cells 0-31 left half, 32-63 right half); every wave reads the 64 flows: wave 0 files the per-cell
+    // arrays, each wave derives its share of the fraction table from them in registers
+    const int my_gi = row0 + cell_row(lane), my_gj = col0 + cell_col(lane);
+    const bool my_ok = (my_gi < G) & (my_gj < G);
+    float my_nx, my_ny;
+    {
+        const rsrc_t flr = make_rsrc(p.flow + (size_t)b * 2 * G * G, 2u * GG4);
+        const unsigned fo = my_ok ? (unsigned)(my_gi * G + my_gj) * 4u : 0u;
+        my_nx = buf_ld(flr, fo, 0u);
+        my_ny = buf_ld(flr, fo, GG4);
+    }
+    // the tile's f0 block: wave w takes channels w, w+8, ...; lane -> tile row lane >> 4, column lane & 15, so a load is four
+    // 64-byte row segments at scalar plane offset + the lane's grid offset
+    constexpr int NF0 = C / kWaves;
+    float f0v[NF0];
+    const int fr = lane >> 4, fc = lane & 15;
+    const bool fok = (row0 + fr < G) & (col0 + fc < G);
+    {
+        const unsigned fgoff = fok ? (unsigned)((row0 + fr) * G + col0 + fc) * 4u : 0u;
+        const rsrc_t f0r = make_rsrc(p.f0 + (size_t)b * p.f0_bs, (unsigned)C * GG4);
+#pragma unroll
+        for (int k = 0; k < NF0; ++k) f0v[k] = buf_ld(f0r, fgoff, (unsigned)(wave + k * kWaves) * GG4);
+    }
+    QuadLane ql;
+    {
+        const float inv_nq = __builtin_amdgcn_rcpf((float)max(u.nq, 1));
+        ql.ry = (int)(((float)lane + 0.5f) * inv_nq);  // lane / nq, exact for these sizes
+        const int q = lane - ql.ry * u.nq;
+        ql.slot = ql.ry * u.pitch + 4 * q;
+        ql.xmask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ql.xmask |= ((unsigned)(u.x0 + 4 * q + k) < (unsigned)W ? 1u : 0u) << k;
+        // border tiles (W % 4 == 0 there, see the plan launch): x0 is a multiple of 4, so a quad lies entirely inside or
+        // entirely outside the image; outside ones point at column 0 and are zeroed by the mask
+        ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * 4u;
+    }
+    const rsrc_t f1r = make_rsrc(f1_of(p, b), (unsigned)C * (unsigned)(H * W) * 4u);
+    constexpr int PRE = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
+    QuadRegs<PRE> pre;
+    quad_issue<PRE, CHECK>(pre, f1r, 0u, H, W, u, wave, ql, 0);
+    STAMP(1);
+
+    // ---- per-cell set-up (wave 0), fraction table, f0 block and first chunk -> LDS ----------------------------------------
+    const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
+    // fraction table: the reference's fp32 coordinate of every tap column / row of every cell (local_correlation.py:55
+    // adds window offsets in normalised units, grid_sample un-normalises).  lane = cell, wave = tap index: no division.
+    bool tab_bad = false;
+    constexpr int NTAB = (2 * D + kWaves - 1) / kWaves;
+#pragma unroll
+    for (int n = 0; n < NTAB; ++n) {
+        const int a = wave + n * kWaves;   // scalar
+        if (a < 2 * D) {
+            const bool isy = a >= D;
+            const int k = isy ? a - D : a;
+            const float lin = isy ? gfn::linspace_step_at(ylo, yhi, p.win_ystep, D, k) : gfn::linspace_step_at(xlo, xhi, p.win_xstep, D, k);
+            const float pix = unnorm((isy ? my_ny : my_nx) + lin, isy ? H : W);
+            const float fl = floorf(pix);
+            const int origin = isy ? c.Y0 : c.X0;
+            // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
+            tab_bad |= (origin != kFar) & !(fl == (float)(origin + k));
+            tab[lane * TS + a] = pix - fl;
+        }
+    }
+    if (wave == 0) {
+        cellX0[lane] = c.X0;
+        cellY0[lane] = c.Y0;
+        cellNx[lane] = my_ok ? my_nx : 0.f;
+        cellNy[lane] = my_ok ? my_ny : 0.f;
+        cellFlag[lane] = c.flag;
+        const unsigned long long slow_mask = __ballot(c.flag == kCellSlow);
+        if (lane == 0) hdr[4] = __popcll(slow_mask);
+    }
+    {
+        const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
+#pragma unroll
+        for (int k = 0; k < NF0; ++k) f0s[fcell * CS + wave + k * kWaves] = fok ? f0v[k] : 0.f;
+    }
+    STAMP(2);
+    quad_commit<PRE, CHECK>(s4, pre, H, u, wave, ql, 0);
+    quad_rest<CHECK>(s4, f1r, 0u, H, W, u, wave, ql, PRE);
+    STAMP(3);
+    __syncthreads();
+    STAMP(4);
+    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+
+    // ---- per-lane D-stage addressing ---------------------------------------------------------------------------------
+    int g, s16;
+    lane_group(lane, g, s16);
+    const int cr = wave * 4 + g;  // cell inside a half (0..31)
+    unsigned apk[ROUNDS][(NP + 1) / 2];
+    float acc[ROUNDS][NP];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int cell = rd * 32 + cr;
+        const int X0 = cellX0[cell], Y0 = cellY0[cell];
+        // cells without a patch (off the grid, flagged, empty) read slot 0 onwards: valid memory, result unused
+        const int base = X0 != kFar ? (Y0 - u.y0) * u.pitch + (X0 - u.x0) : 0;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            acc[rd][t] = 0.f;
+            const int pp = s16 + 16 * t;
+            const int yy = DivPW<PW>::div(pp), xx = pp - yy * PW;
+            int slot = base + yy * u.pitch + xx;
+            if (16 * t + 15 >= P) slot = pp < P ? slot : 0;  // positions past the patch (last pass only)
+            const unsigned a = (unsigned)(slot * kSlotV4);
+            if (t & 1)
+                apk[rd][t >> 1] |= a << 16;
+            else
+                apk[rd][t >> 1] = a;
+        }
+    }
+    STAMP(5);
+
+    // ---- main loop: 16 channels at a time ----------------------------------------------------------------------------
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = ch * kChunk;
+        const unsigned next_off = (unsigned)(c0 + kChunk) * (unsigned)(H * W) * 4u;  // byte offset of the next chunk's first plane
+        constexpr bool kUnused = false; (void)kUnused;
+        const bool more = ch + 1 < NCH;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+            for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
+        if (more) quad_issue<PRE, CHECK>(pre, f1r, next_off, H, W, u, wave, ql, 0);  // next chunk's loads: in flight across this chunk's D-stage
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            float f[kChunk];
+            {
+                const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + c0);
+                const float4 a0 = fq[0], a1 = fq[1], a2 = fq[2], a3 = fq[3];
+                f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+                f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w; f[12] = a3.x; f[13] = a3.y; f[14] = a3.z; f[15] = a3.w;
+            }
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
+                const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                float a = acc[rd][t];
+                a = fmaf(f[0], v0.x, a);  a = fmaf(f[1], v0.y, a);  a = fmaf(f[2], v0.z, a);  a = fmaf(f[3], v0.w, a);
+                a = fmaf(f[4], v1.x, a);  a = fmaf(f[5], v1.y, a);  a = fmaf(f[6], v1.z, a);  a = fmaf(f[7], v1.w, a);
+                a = fmaf(f[8], v2.x, a);  a = fmaf(f[9], v2.y, a);  a = fmaf(f[10], v2.z, a); a = fmaf(f[11], v2.w, a);
+                a = fmaf(f[12], v3.x, a); a = fmaf(f[13], v3.y, a); a = fmaf(f[14], v3.z, a); a = fmaf(f[15], v3.w, a);
+                acc[rd][t] = a;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+            for (int t = 0; t < NP; ++t) asm volatile("" : "+v"(acc[rd][t]));  // pins the FMAs above this point
+        STAMP(ch == 0 ? 6 : 9);
+        if (more) {
+            __syncthreads();  // everyone is done reading this chunk
+            STAMP(7);
+            quad_commit<PRE, CHECK>(s4, pre, H, u, wave, ql, 0);
+            quad_rest<CHECK>(s4, f1r, next_off, H, W, u, wave, ql, PRE);
+            __syncthreads();
+            STAMP(8);
+        }
+    }
+
+    // ---- epilogue: D -> LDS, bilinear combination, coalesced stores ----------------------------------------------------
+    __syncthreads();
+    STAMP(10);
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int cell = rd * 32 + cr;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const int pp = s16 + 16 * t;
+            if (pp < P) dbuf[cell * DS + pp] = acc[rd][t];
+        }
+    }
+    STAMP(11);
+    __syncthreads();
+    STAMP(12);
+    {
+        // lane -> cell so that a wave stores whole 64-byte grid-row segments: tile row lane >> 4, column lane & 15
+        const int er = lane >> 4, ec = lane & 15;
+        const int cell = ((ec >> 3) << 5) | (er << 3) | (ec & 7);
+        const int gi = row0 + er, gj = col0 + ec;
+        const int flag = cellFlag[cell];
+        if ((gi < G) & (gj < G) & !(flag & kCellSlow)) {
+            const bool empty = (flag & kCellEmpty) != 0;
+            const float *dc = dbuf + cell * DS;
+            const float *tc = tab + cell * TS;
+            const unsigned goff = (unsigned)(gi * G + gj) * 4u;
+            const rsrc_t outr = make_rsrc(p.out + (size_t)b * p.out_bs, (unsigned)K * GG4);
+            float wx1[D], wx0[D];
+#pragma unroll
+            for (int kx = 0; kx < D; ++kx) { wx1[kx] = tc[kx]; wx0[kx] = 1.f - wx1[kx]; }
+            constexpr int NR = (D + kWaves - 1) / kWaves;
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int ky = wave + n * kWaves;  // scalar
+                if (ky < D) {
+                    // separable bilinear: the PW patch columns are blended vertically once (1/sqrt(C) folded into the row
+                    // weights), every tap is then two instructions
+                    const float wy1 = tc[D + ky];
+                    const float wy1s = wy1 * p.inv_sqrt_c, wy0s = (1.f - wy1) * p.inv_sqrt_c;
+                    const float *d = dc + ky * PW;
+                    float m[PW];
+#pragma unroll
+                    for (int x = 0; x < PW; ++x) m[x] = fmaf(d[PW + x], wy1s, d[x] * wy0s);
+#pragma unroll
+                    for (int kx = 0; kx < D; ++kx) {
+                        const float val = fmaf(m[kx + 1], wx1[kx], m[kx] * wx0[kx]);
+                        buf_st_nt(outr, goff, (unsigned)(ky * D + kx) * GG4, empty ? 0.f : val);  // streamed: nothing on the hot path reads it back
+                    }
+                }
+            }
+        }
+    }
+    STAMP(13);
+#ifdef GFN_ABLATE
+    if (stamping)
+        printf("lean r%d wave %d (cycles from entry): all issued %lld | cells+table+f0 in LDS %lld | stage0 committed %lld | barrier %lld | addressing %lld | "
+               "D0 %lld | barrier %lld | stage1 committed+barrier %lld | D1 %lld | barrier %lld | dbuf %lld | barrier %lld | stores issued %lld\n",
+               R, tid >> 6, stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0],
+               stamp[7] - stamp[0], stamp[8] - stamp[0], stamp[9] - stamp[0], stamp[10] - stamp[0], stamp[11] - stamp[0], stamp[12] - stamp[0],
+               stamp[13] - stamp[0]);
+#endif
+
+    // ---- flagged cells: general per-tap routine (about one cell in 10^4) ---------------------------------------------
+    const int nslow = __builtin_amdgcn_readfirstlane(hdr[4]);
+    if (nslow != 0) {  // block-uniform, rare
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int cell = 0; cell < NC; ++cell)
+                if ((cellFlag[cell] & kCellSlow) && (row0 + cell_row(cell) < G) && (col0 + cell_col(cell) < G)) cellX0[n++] = cell;
+            hdr[4] = n;
+            atomicAdd(p.todo + 4, n);  // informational (bench.py: flagged_cell_frac)
+        }
+        __syncthreads();
+        const int total = hdr[4] * K;
+        for (int e = tid; e < total; e += kThreads) {
+            const int cell = cellX0[e / K], k = e % K;
+            const int gi = row0 + cell_row(cell), gj = col0 + cell_col(cell);
+            p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
+                tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
+        }
+    }
+}
+
+template <int R, int NCH>
+__global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
+    // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
+    // have in the vector-memory pipeline
+    i32x4 plan_v;
+    {
+        const int *pp = p.plan + (size_t)wid * kPlanInts;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(plan_v) : "s"(pp) : "memory");
+    }
+    if (plan_v.w & kPlanSecond) return;  // the plan launch has put this tile on the second launch's list (block-uniform)
+    RowPlan u;
+    u.x0 = plan_v.x;
+    u.y0 = plan_v.y;
+    u.w = plan_v.z & 0xffff; u.h = plan_v.z >> 16;
+    (void)region_fits<R>(u);          // pitch, quads per row, rows per item, items (the plan launch checked that it fits)
+    if (plan_v.w & kPlanInterior)
+        lean_tile<R, NCH, false>(p, smem, u, wid, tid, lane, wave);
+    else
+        lean_tile<R, NCH, true>(p, smem, u, wid, tid, lane, wave);
+}

@@ -105,6 +105,40 @@ def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
     assert_close(out, ref, TOL, f"c{c} hs{hs} G{G} r{r} {flow_kind}")
 
 
+@pytest.mark.parametrize("c,hs,G,r", [(32, 112, 64, 4), (16, 224, 128, 2), (32, 140, 80, 4), (16, 280, 160, 2), (16, 60, 40, 3), (16, 30, 24, 1),
+                                      (32, 168, 96, 4), (16, 336, 192, 2)])
+@pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random", "border", "rot"])
+def test_lean_tile_kernel_is_bit_identical_to_round1_kernel(c, hs, G, r, flow_kind):
+    """The round-2 lean tile kernel (variant 0, r <= 4) keeps the round-1 kernel's arithmetic (same D accumulation order, same
+    epilogue): the two must agree bit for bit, whatever path a tile takes (staged, second launch, per-tap, empty windows)."""
+    B = 4
+    f0 = synth.lattice_normalish((B, c, G, G), 231 + r)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 232 + r)
+    if flow_kind == "homography":
+        flow = synth.homography_flow(B, G, 233)
+    elif flow_kind == "zoom":
+        flow = synth.homography_flow(B, G, 234, scale=1.7)
+    elif flow_kind == "random":
+        flow = 1.2 * synth.lattice_uniform((B, 2, G, G), 235)
+    elif flow_kind == "border":  # shifted so that a band of windows hangs over / leaves the image on every side
+        flow = synth.homography_flow(B, G, 236, scale=1.02)
+        flow[0, 0] += np.float32(0.35); flow[1, 0] -= np.float32(0.4); flow[2, 1] += np.float32(0.3); flow[3, 1] -= np.float32(0.45)
+    else:  # rotations by 10..40 degrees about the centre
+        lin = (np.arange(G, dtype=np.float64) * 2 + 1) / G - 1
+        gy, gx = np.meshgrid(lin, lin, indexing="ij")
+        flow = np.empty((B, 2, G, G), np.float32)
+        for b in range(B):
+            a = np.deg2rad(10.0 * (b + 1))
+            flow[b, 0] = (np.cos(a) * gx - np.sin(a) * gy) * 0.9
+            flow[b, 1] = (np.sin(a) * gx + np.cos(a) * gy) * 0.9
+        flow += np.float32(0.002) * synth.lattice_uniform((B, 2, G, G), 237)
+    lean = run(f0, f1, flow, r, G)
+    old = run(f0, f1, flow, r, G, _variant=2)
+    np.testing.assert_array_equal(lean, old)
+    if flow_kind in ("border", "rot"):
+        assert_close(lean, oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
+
+
 def test_ragged_sizes_and_rect_maps():
     # G not a multiple of the tile, rectangular f1, batch of 3
     B, c, h, w, G, r = 3, 16, 37, 53, 21, 3

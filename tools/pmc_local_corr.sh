@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): bash tools/pmc_local_corr.sh C HS G R  -> SQ counters of the tile kernel, per dispatch
 C=$1; HS=$2; G=$3; R=$4
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/pmc_lc_r$R
+OUT=$ROOT/gpurun_out/pmc_lc_r${R}_v${VARIANT:-0}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -24,5 +24,6 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
 for k, d in agg.items():
     if "local_corr_tile" in k:
         print(k)
-        for c, v in sorted(d.items()): print(f"   {c:28s} per dispatch {sum(v)/len(v):.5g}  (n={len(v)})")
+        w = sum(d["SQ_WAVES"]) / len(d["SQ_WAVES"]) if "SQ_WAVES" in d else 1
+        for c, v in sorted(d.items()): print(f"   {c:28s} per dispatch {sum(v)/len(v):.5g}  per wave {sum(v)/len(v)/w:.5g} (n={len(v)})")
 PY

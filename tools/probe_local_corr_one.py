@@ -18,7 +18,8 @@ f0 = torch.randn(B, c, G, G, device="cuda")
 f1 = torch.randn(B, c, hs, hs, device="cuda")
 flow = torch.from_numpy(np.tile(synth.homography_flow(2, G, 5), (B // 2, 1, 1, 1))).cuda()
 out = torch.empty(B, (2 * r + 1) ** 2, G, G, device="cuda")
+variant = int(os.environ.get("VARIANT", "0"))  # 0: lean tile kernel (r <= 4), 2: round-1 tile kernel
 for _ in range(reps):
-    local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow, out=out)
+    local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow, out=out, _variant=variant)
 torch.cuda.synchronize()
 print("done")
