@@ -49,7 +49,7 @@ constexpr int kMaxLds = 150 * 1024;       // dynamic LDS a tiled launch may ask 
 constexpr int kFar = 1 << 28;             // patch origin of a cell that samples nothing
 constexpr int kTodoHdr = 8;               // ints in front of the tile list in scratch: [0] tiles left to the second launch, [1] its queue head,
                                           // [2] its finished workgroups, [3] last call's [0], [4] cells redone per tap (running call),
-                                          // [5] last call's [4], [6..7] spare; [0..2] and [4] are zero between calls
+                                          // [5] last call's [4], [6] tiles staged in halves (running call), [7] last call's [6]; [0..2], [4] and [6] are zero between calls
 
 struct LcParams {
     const float *f0;
@@ -798,6 +798,8 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
         p.todo[3] = p.todo[0];  // informational (tools/count_irregular.py, bench.py)
         p.todo[5] = p.todo[4];
         p.todo[4] = 0;
+        p.todo[7] = p.todo[6];
+        p.todo[6] = 0;
         p.todo[0] = 0;
         p.todo[1] = 0;
         p.todo[2] = 0;
@@ -880,7 +882,7 @@ GFN_EXPORT int64_t gfn_local_corr_scratch_bytes(int B, int G) {
     // smallest tile is 2 x 16 cells -> at most B * ceil(G/2) * ceil(G/16) tiles, plus the counter
     const int64_t tiles = (int64_t)((G + 1) / 2) * ((G + 15) / 16);
     // header + tile list (ints), then the lean path's plan (16 bytes per tile, 16-byte aligned)
-    return 4 * ((int64_t)B * tiles + kTodoHdr) + 16 + 16 * (int64_t)B * tiles;
+    return 4 * ((int64_t)B * tiles + kTodoHdr) + 32 + 4 * kPlanInts * (int64_t)B * tiles;
 }
 
 GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second,
@@ -926,7 +928,7 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     bool lean = variant == 0 && flow && (C == 16 || C == 32 || C == 64) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
     if (lean && scratch) {
         const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
-        const uintptr_t pl = ((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 15) & ~(uintptr_t)15;
+        const uintptr_t pl = ((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 31) & ~(uintptr_t)31;
         p.plan = reinterpret_cast<int *>(pl);
         p.todo_ints = tiles_max + kTodoHdr;
     }

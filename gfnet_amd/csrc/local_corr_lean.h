@@ -23,8 +23,14 @@
 //   * tile = two 4 x 8-cell halves (cells 0-31 / 32-63), the epilogue still stores 64-byte row segments;
 //   * fraction table: lane = cell, wave = tap index (no division); stores use scalar plane offsets.
 
-constexpr int kPlanInts = 4;  // per tile: region x0 (multiple of 4 when W is), y0, (h << 16) | w, flags
-constexpr int kPlanInterior = 1, kPlanSecond = 2;
+#ifndef GFN_LEAN_STAGE2_KB
+#define GFN_LEAN_STAGE2_KB 40
+#endif
+constexpr int kPlanInts = 8;  // per tile: region A x0, y0, (h << 16) | w, flags; region B x0, y0, (h << 16) | w, spare
+constexpr int kPlanInterior = 1, kPlanSecond = 2, kPlanHalves = 4;
+// flags: kPlanInterior -- no staged pixel lies outside the image; kPlanSecond -- the tile is on the second launch's list;
+// kPlanHalves -- the windows of the whole tile do not fit the stage, those of its two 4 x 8-cell halves do: region A serves
+// cells 0-31, region B cells 32-63, staged one after the other (otherwise region A serves all 64 cells)
 
 // cell id inside a tile -> (row, column): cells 0-31 are the left 4 x 8 half, 32-63 the right one
 __device__ __forceinline__ int cell_row(int c) { return (c & 31) >> 3; }
@@ -34,9 +40,9 @@ __device__ __forceinline__ int cell_col(int c) { return (c & 7) + ((c >> 5) << 3
 // 40 KB three workgroups fit a CU
 template <int R>
 struct Lean {
-    static constexpr int kStage = R <= 2 ? 40 * 1024 : 64 * 1024;  // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU
+    static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : 64 * 1024;  // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU
     static constexpr int kCap = kStage / (kSlotV4 * 16);
-    static constexpr int kMinWaves = R <= 2 ? 6 : 4;  // waves per SIMD the register allocation must allow
+    static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
 };
 
@@ -127,31 +133,54 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
         const unsigned wid = wid0 + t;
         if (wid >= total) break;
         const CellBox c = cell_box<PW>(ok[t], nx[t], ny[t], -p.win_xhi, -p.win_yhi, p.W, p.H);
-        const int bx0 = wave_min_i32(c.bx0), by0 = wave_min_i32(c.by0);
-        const int bx1 = -wave_min_i32(-c.bx1), by1 = -wave_min_i32(-c.by1);
+        // boxes of the two halves (lanes 0-31 / 32-63), the tile's box is their union
+        const bool left = lane < 32;
+        int hx0[2], hy0[2], hx1[2], hy1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool mine = left == (h == 0);
+            hx0[h] = wave_min_i32(mine ? c.bx0 : kFar);
+            hy0[h] = wave_min_i32(mine ? c.by0 : kFar);
+            hx1[h] = -wave_min_i32(mine ? -c.bx1 : kFar);
+            hy1[h] = -wave_min_i32(mine ? -c.by1 : kFar);
+        }
         const bool all_in = __all(c.inside);
         if (lane == 0) {
-            RowPlan u;
-            // 16-byte aligned quads (region starting on a multiple of 4 pixels, rows and planes multiples of 4 too) where that
-            // is free, i.e. does not add a quad per row -- an extra quad pushes the row pitch to the next conflict-free value
-            // (16 slots more) or the region out of the stage.  Border tiles need the alignment (whole-quad masks).
-            u.x0 = bx0;
-            if ((p.W & 3) == 0) {
-                const int xa = bx0 & ~3;
-                if (!all_in || ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2)) u.x0 = xa;
-            }
-            u.y0 = by0;
-            u.w = max(bx1 - u.x0, 0);
-            u.h = max(by1 - by0, 0);
-            if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
+            auto region = [&](int bx0, int by0, int bx1, int by1, RowPlan &u) {
+                // 16-byte aligned quads (region starting on a multiple of 4 pixels, rows and planes multiples of 4 too) where
+                // that is free, i.e. does not add a quad per row -- an extra quad pushes the row pitch to the next
+                // conflict-free value (16 slots more) or the region out of the stage.  Border tiles need the alignment
+                // (whole-quad masks).
+                u.x0 = bx0;
+                if ((p.W & 3) == 0) {
+                    const int xa = bx0 & ~3;
+                    if (!all_in || ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2)) u.x0 = xa;
+                }
+                u.y0 = by0;
+                u.w = max(bx1 - u.x0, 0);
+                u.h = max(by1 - by0, 0);
+                if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
+                return region_fits<R>(u);
+            };
+            RowPlan ua, ub;
             // border tiles are staged with whole-quad masks, which needs rows that are multiples of 4 pixels: otherwise (no
             // production shape) the tile goes to the second launch
-            const bool fits = region_fits<R>(u) && (all_in || (p.W & 3) == 0);
-            const int flags = (all_in ? kPlanInterior : 0) | (fits ? 0 : kPlanSecond);
-            int4 pl;
-            pl.x = u.x0; pl.y = u.y0; pl.z = (u.h << 16) | u.w; pl.w = flags;
-            reinterpret_cast<int4 *>(p.plan)[wid] = pl;
-            if (!fits) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;  // strong magnification / scattered flow: second launch
+            const bool border_ok = all_in || (p.W & 3) == 0;
+            int flags = all_in ? kPlanInterior : 0;
+            const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
+            ub = ua;
+            if (!full) {
+                const bool fa = region(hx0[0], hy0[0], hx1[0], hy1[0], ua), fb = region(hx0[1], hy0[1], hx1[1], hy1[1], ub);
+                flags |= (fa && fb && border_ok) ? kPlanHalves : kPlanSecond;
+            }
+            int4 pl0, pl1;
+            pl0.x = ua.x0; pl0.y = ua.y0; pl0.z = (ua.h << 16) | ua.w; pl0.w = flags;
+            pl1.x = ub.x0; pl1.y = ub.y0; pl1.z = (ub.h << 16) | ub.w; pl1.w = 0;
+            reinterpret_cast<int4 *>(p.plan)[2 * wid] = pl0;
+            reinterpret_cast<int4 *>(p.plan)[2 * wid + 1] = pl1;
+            if (flags & kPlanSecond) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;  // strong magnification / scattered flow: second launch
+            else if ((flags & kPlanHalves) && (wid & 15u) == 0) atomicAdd(p.todo + 6, 16);  // informational, sampled: an atomic per tile
+                                                                                            // on one word costs ~11 ns each
         }
     }
 }
@@ -263,8 +292,11 @@ struct DivPW {
 // One tile.  CHECK: the region sticks out of the image (border tiles).  Everything that loads from global memory is
 // straight-line code (no branches around loads), so that the compiler's wait counts stay exact: with conditional loads it
 // falls back to vmcnt(0) and the cell set-up ends up waiting for the stage loads issued after it.
-template <int R, int NCH, bool CHECK>
-__device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &u, unsigned wid, int tid, int lane, int wave) {
+// HALVES: the tile is staged as two 4 x 8-cell halves, one after the other (region uA for cells 0-31 = round 0, uB for cells
+// 32-63 = round 1); otherwise uA serves both rounds.
+template <int R, int NCH, bool CHECK, bool HALVES>
+__device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, unsigned wid, int tid,
+                                          int lane, int wave) {
     constexpr int ROUNDS = 2;
     constexpr int C = 16 * NCH;
     constexpr int kStageBytes = Lean<R>::kStage;  // shadows the round-1 constant
@@ -324,8 +356,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
         for (int k = 0; k < NF0; ++k) f0v[k] = buf_ld(f0r, fgoff, (unsigned)(wave + k * kWaves) * GG4);
     }
-    QuadLane ql;
-    {
+    auto quad_lane = [&](const RowPlan &u) {
+        QuadLane ql;
         const float inv_nq = __builtin_amdgcn_rcpf((float)max(u.nq, 1));
         ql.ry = (int)(((float)lane + 0.5f) * inv_nq);  // lane / nq, exact for these sizes
         const int q = lane - ql.ry * u.nq;
@@ -336,12 +368,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         // border tiles (W % 4 == 0 there, see the plan launch): x0 is a multiple of 4, so a quad lies entirely inside or
         // entirely outside the image; outside ones point at column 0 and are zeroed by the mask
         ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * 4u;
-    }
+        return ql;
+    };
+    const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of(p, b), (unsigned)C * (unsigned)(H * W) * 4u);
     constexpr int PRE = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
     QuadRegs<PRE> pre;
-    quad_issue<PRE, CHECK>(pre, f1r, 0u, H, W, u, wave, ql, 0);
+    quad_issue<PRE, CHECK>(pre, f1r, 0u, H, W, uA, wave, qlA, 0);
     STAMP(1);
+    const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
     // ---- per-cell set-up (wave 0), fraction table, f0 block and first chunk -> LDS ----------------------------------------
     const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
@@ -379,8 +414,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int k = 0; k < NF0; ++k) f0s[fcell * CS + wave + k * kWaves] = fok ? f0v[k] : 0.f;
     }
     STAMP(2);
-    quad_commit<PRE, CHECK>(s4, pre, H, u, wave, ql, 0);
-    quad_rest<CHECK>(s4, f1r, 0u, H, W, u, wave, ql, PRE);
+    quad_commit<PRE, CHECK>(s4, pre, H, uA, wave, qlA, 0);
+    quad_rest<CHECK>(s4, f1r, 0u, H, W, uA, wave, qlA, PRE);
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -396,6 +431,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
         const int X0 = cellX0[cell], Y0 = cellY0[cell];
+        const RowPlan &u = (HALVES && rd == 1) ? uB : uA;
         // cells without a patch (off the grid, flagged, empty) read slot 0 onwards: valid memory, result unused
         const int base = X0 != kFar ? (Y0 - u.y0) * u.pitch + (X0 - u.x0) : 0;
 #pragma unroll
@@ -414,20 +450,26 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
     STAMP(5);
 
-    // ---- main loop: 16 channels at a time ----------------------------------------------------------------------------
+    // ---- main loop: 16 channels at a time (per half when the tile is staged in halves) ------------------------------------
+    constexpr int NS = HALVES ? 2 * NCH : NCH;  // steps: (half, chunk)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int st = 0; st < NS; ++st) {
+        const int ch = HALVES ? st % NCH : st;          // compile-time after unrolling
+        const int half = HALVES ? st / NCH : 0;
         const int c0 = ch * kChunk;
-        const unsigned next_off = (unsigned)(c0 + kChunk) * (unsigned)(H * W) * 4u;  // byte offset of the next chunk's first plane
-        constexpr bool kUnused = false; (void)kUnused;
-        const bool more = ch + 1 < NCH;
+        const bool more = st + 1 < NS;
+        const int nch = HALVES ? (st + 1) % NCH : st + 1, nhalf = HALVES ? (st + 1) / NCH : 0;
+        const unsigned next_off = (unsigned)(nch * kChunk) * (unsigned)(H * W) * 4u;  // byte offset of the next step's first plane
+        const RowPlan &un = (HALVES && nhalf == 1) ? uB : uA;
+        const QuadLane &qn = (HALVES && nhalf == 1) ? qlB : qlA;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) quad_issue<PRE, CHECK>(pre, f1r, next_off, H, W, u, wave, ql, 0);  // next chunk's loads: in flight across this chunk's D-stage
+        if (more) quad_issue<PRE, CHECK>(pre, f1r, next_off, H, W, un, wave, qn, 0);  // next step's loads: in flight across this D-stage
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
+            if (HALVES && rd != half) continue;
             float f[kChunk];
             {
                 const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + c0);
@@ -452,12 +494,12 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int t = 0; t < NP; ++t) asm volatile("" : "+v"(acc[rd][t]));  // pins the FMAs above this point
-        STAMP(ch == 0 ? 6 : 9);
+        STAMP(st == 0 ? 6 : 9);
         if (more) {
-            __syncthreads();  // everyone is done reading this chunk
+            __syncthreads();  // everyone is done reading this step's pixels
             STAMP(7);
-            quad_commit<PRE, CHECK>(s4, pre, H, u, wave, ql, 0);
-            quad_rest<CHECK>(s4, f1r, next_off, H, W, u, wave, ql, PRE);
+            quad_commit<PRE, CHECK>(s4, pre, H, un, wave, qn, 0);
+            quad_rest<CHECK>(s4, f1r, next_off, H, W, un, wave, qn, PRE);
             __syncthreads();
             STAMP(8);
         }
@@ -555,19 +597,25 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
     // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
     // have in the vector-memory pipeline
-    i32x4 plan_v;
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    i32x8 pl;
     {
         const int *pp = p.plan + (size_t)wid * kPlanInts;
-        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(plan_v) : "s"(pp) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pl) : "s"(pp) : "memory");
     }
-    if (plan_v.w & kPlanSecond) return;  // the plan launch has put this tile on the second launch's list (block-uniform)
-    RowPlan u;
-    u.x0 = plan_v.x;
-    u.y0 = plan_v.y;
-    u.w = plan_v.z & 0xffff; u.h = plan_v.z >> 16;
-    (void)region_fits<R>(u);          // pitch, quads per row, rows per item, items (the plan launch checked that it fits)
-    if (plan_v.w & kPlanInterior)
-        lean_tile<R, NCH, false>(p, smem, u, wid, tid, lane, wave);
-    else
-        lean_tile<R, NCH, true>(p, smem, u, wid, tid, lane, wave);
+    const int flags = pl[3];
+    if (flags & kPlanSecond) return;  // the plan launch has put this tile on the second launch's list (block-uniform)
+    RowPlan uA, uB;
+    uA.x0 = pl[0]; uA.y0 = pl[1]; uA.w = pl[2] & 0xffff; uA.h = pl[2] >> 16;
+    uB.x0 = pl[4]; uB.y0 = pl[5]; uB.w = pl[6] & 0xffff; uB.h = pl[6] >> 16;
+    (void)region_fits<R>(uA);         // pitch, quads per row, rows per item, items (the plan launch checked that they fit)
+    (void)region_fits<R>(uB);
+    const bool interior = (flags & kPlanInterior) != 0;
+    if (flags & kPlanHalves) {
+        if (interior) lean_tile<R, NCH, false, true>(p, smem, uA, uB, wid, tid, lane, wave);
+        else lean_tile<R, NCH, true, true>(p, smem, uA, uB, wid, tid, lane, wave);
+    } else {
+        if (interior) lean_tile<R, NCH, false, false>(p, smem, uA, uB, wid, tid, lane, wave);
+        else lean_tile<R, NCH, true, false>(p, smem, uA, uB, wid, tid, lane, wave);
+    }
 }

@@ -19,6 +19,11 @@ def _L():
 # bench.py sets this to a dict {name: [(start_event, end_event), ...]} to time individual launches
 # with HIP events on the launch stream; None (the default) costs nothing.
 kernel_events = None
+# bench.py / tools set this to a dict to collect, per local-correlation call (name -> [(tiles left to the second launch,
+# cells redone per tap, tiles staged in halves), ...]), the counters the kernels leave in the scratch header; costs a device sync per call.
+kernel_counters = None
+# True once the kernels read fp16 feature maps directly (BASELINE config 5); until then fp16 inputs are widened by a cast
+NATIVE_FP16 = False
 
 
 def _timed(name, launch):
@@ -100,10 +105,13 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
         out = d[:, 2 * C + Dd:]
         nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
         scr = _lib.scratch(dev, nscr)
-        check(_timed(f"local_corr_c{C}_h{Hs}_g{G}_r{r}",
-                     lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, ptr(fl),
-                                                     c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws,
-                                                     ptr(scr), nscr, st)), "gfn_local_corr_fwd")
+        name = f"local_corr_c{C}_h{Hs}_g{G}_r{r}"
+        check(_timed(name, lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, ptr(fl),
+                                                           c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws,
+                                                           ptr(scr), nscr, st)), "gfn_local_corr_fwd")
+        if kernel_counters is not None:
+            hdr = scr[:8].cpu()  # synchronises; header layout: csrc/local_corr.hip kTodoHdr
+            kernel_counters.setdefault(name, []).append((int(hdr[3]), int(hdr[5]), int(hdr[7])))
     return d
 
 
