@@ -202,7 +202,7 @@ class Scene:
         return Hl, good
 
     # ---- the same stages through the C/OpenMP oracle on pair b (host cores) --------------------------------
-    def cpu_pair(self, b, np_pyr, np_up, np_gt, np_noise, seed):
+    def cpu_pair(self, b, np_pyr, np_up, np_gt, np_noise, seed, return_all=False):
         import oracle
 
         m, nb = self.model, self.B
@@ -228,7 +228,9 @@ class Scene:
                                          corr_in_other=radii[i] > 0)
                     target = np_gt[G][[b, b + nb]] + np_noise[G][itr][[b, b + nb]]
                     dl = (target - flow) * np.float32(4.0 * size / int(s))
-                    flow, cert, disp_prev = oracle.flow_update(flow, cert, dl, np.ones_like(cert), disp_prev, int(s), size, size)
+                    flow, cert, disp_prev, rel = oracle.flow_update(flow, cert, dl, np.ones_like(cert), disp_prev, int(s), size, size,
+                                                                    return_rel=True)
+                    res[(s, itr + 1)] = (flow, cert, rel)
                 res[s] = (flow, cert)
                 if s != "1":
                     flow = oracle.interpolate_bilinear(flow, grids[i + 1])
@@ -239,6 +241,8 @@ class Scene:
         gu, ru, iu = m.upsample_grids(self.up)
         r2 = run_pass(np_up[0], np_up[1], self.up, gu, ru, iu, SCALES[1:], pre=r1["1"], sf=math.sqrt(self.up * self.up / (self.size * self.size)))
         warp, cert = oracle.match_post(r2["1"][0], r2["1"][1], r1["16"][1], symmetric=True, attenuate_cert=True)
+        if return_all:
+            return r1, r2, warp, cert
         torch.manual_seed(1234 + b)
         good, _ = oracle.sample(warp[0], cert[0], num=5000, device_is_gpu=True)
         pts = oracle.convert_matches(good, *self.sizes)

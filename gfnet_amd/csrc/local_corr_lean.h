@@ -147,14 +147,15 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
         const bool all_in = __all(c.inside);
         if (lane == 0) {
             auto region = [&](int bx0, int by0, int bx1, int by1, RowPlan &u) {
-                // 16-byte aligned quads (region starting on a multiple of 4 pixels, rows and planes multiples of 4 too) where
-                // that is free, i.e. does not add a quad per row -- an extra quad pushes the row pitch to the next
-                // conflict-free value (16 slots more) or the region out of the stage.  Border tiles need the alignment
-                // (whole-quad masks).
+                // Border tiles: the region starts on a multiple of 4 pixels, so that a quad never straddles the image's left
+                // edge (a quad hanging over the right edge reads on into the next row, or past the tensor where the buffer
+                // returns zeros, and is masked per pixel).  Interior tiles: the same alignment makes the quads 16-byte
+                // aligned when rows are multiples of 4 pixels; taken where it is free, i.e. does not add a quad per row (an
+                // extra quad pushes the row pitch to the next conflict-free value or the region out of the stage).
                 u.x0 = bx0;
-                if ((p.W & 3) == 0) {
+                {
                     const int xa = bx0 & ~3;
-                    if (!all_in || ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2)) u.x0 = xa;
+                    if (!all_in || ((p.W & 3) == 0 && ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2))) u.x0 = xa;
                 }
                 u.y0 = by0;
                 u.w = max(bx1 - u.x0, 0);
@@ -163,9 +164,7 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
                 return region_fits<R>(u);
             };
             RowPlan ua, ub;
-            // border tiles are staged with whole-quad masks, which needs rows that are multiples of 4 pixels: otherwise (no
-            // production shape) the tile goes to the second launch
-            const bool border_ok = all_in || (p.W & 3) == 0;
+            const bool border_ok = true;
             int flags = all_in ? kPlanInterior : 0;
             const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
             ub = ua;
@@ -365,8 +364,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         ql.xmask = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ql.xmask |= ((unsigned)(u.x0 + 4 * q + k) < (unsigned)W ? 1u : 0u) << k;
-        // border tiles (W % 4 == 0 there, see the plan launch): x0 is a multiple of 4, so a quad lies entirely inside or
-        // entirely outside the image; outside ones point at column 0 and are zeroed by the mask
+        // border tiles: x0 is a multiple of 4 (plan launch), so a quad never straddles the left image edge; quads left of the
+        // image point at column 0 and are zeroed by the mask, like the pixels of a quad that hangs over the right edge
         ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * 4u;
         return ql;
     };

@@ -254,9 +254,10 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     return np.concatenate(parts, axis=1)  # :555 / :558
 
 
-def flow_update(flow, certainty, delta_flow, delta_cert, disp_prev, scale, W0, H0, training=False):
+def flow_update(flow, certainty, delta_flow, delta_cert, disp_prev, scale, W0, H0, training=False, return_rel=False):
     """model/network.py:262-268: displacement scaling, eval-time zeroing, accumulation.
-    Returns (flow, certainty, displacement)."""
+    Returns (flow, certainty, displacement) [, rel]: rel = |d - d_prev| / |d_prev|, the quantity the eval-time rule compares
+    with 1e-6 (tests use it to find the cells where that discontinuous rule is decided by the last bit)."""
     f32 = np.float32
     # reference: int(scale) * stack(dx/(4*W0), dy/(4*H0))
     d = np.stack((delta_flow[:, 0].astype(f32) / f32(4 * W0), delta_flow[:, 1].astype(f32) / f32(4 * H0)), axis=1)
@@ -265,7 +266,10 @@ def flow_update(flow, certainty, delta_flow, delta_cert, disp_prev, scale, W0, H
         with np.errstate(divide="ignore", invalid="ignore"):
             rel = np.abs(d - disp_prev) / np.abs(disp_prev)
         d = np.where(rel < f32(1e-6), f32(0), d)
-    return (flow + d).astype(f32), (certainty + delta_cert).astype(f32), d
+    else:
+        rel = np.full_like(d, np.inf)
+    out = ((flow + d).astype(f32), (certainty + delta_cert).astype(f32), d)
+    return out + (rel,) if return_rel else out
 
 
 def match_post(flow, certainty, low_res_certainty16=None, symmetric=True, attenuate_cert=True):
