@@ -19,11 +19,14 @@ c_int, c_i64, c_vp, c_float, c_double = ctypes.c_int, ctypes.c_int64, ctypes.c_v
 _SIGNATURES = {
     "gfn_local_corr_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp, c_i64, c_vp],
     "gfn_local_corr_fwd_ex": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp, c_i64, c_vp],
+    "gfn_local_corr_fwd_dt": [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_i64] + [c_int] * 10 + [c_vp, c_i64, c_vp],
     "gfn_avg_pool2": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "gfn_corr_softargmax_fwd": [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_corr_volume_fwd": [c_vp, c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp],
     "gfn_pos_embed_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_refiner_input_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_vp],
+    "gfn_refiner_input_fwd_dt": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_vp],
+    "gfn_corr_softargmax_fwd_dt": [c_vp, c_vp, c_int, c_vp] + [c_int] * 7 + [c_vp],
     "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
     "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_interp_bilinear_pair_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
@@ -129,6 +132,17 @@ def scratch(device, nbytes):
         buf = torch.zeros((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
         _scratch[key] = buf
     return buf
+
+
+GFN_F32, GFN_F16 = 0, 1
+
+
+def featc(t):
+    """A feature map as the kernels read it: contiguous, fp32 or fp16 as stored (BASELINE config 5: fp16 pyramids are read
+    directly, no widened copy); returns (tensor, dtype code).  Other dtypes (bf16, fp64) are widened to fp32."""
+    if t.dtype == torch.float16:
+        return t.contiguous(), GFN_F16
+    return f32c(t), GFN_F32
 
 
 def f32c(t):

@@ -22,8 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // KS = k-steps of 2 channels held in registers (compile-time so that the operand array stays in
 // VGPRs: a runtime-indexed register array would go to scratch).
-template <int KS, bool WRITE_VOL, bool WRITE_FLOW>
-__global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+// FT: storage type of the feature maps (float, or _Float16 for BASELINE config 5: widened on load, products and sums fp32)
+template <int KS, bool WRITE_VOL, bool WRITE_FLOW, typename FT>
+__global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restrict__ f0, const FT *__restrict__ f1,
                                                               float *__restrict__ vol, float *__restrict__ flow, int B,
                                                               int Bh, int C, int H0, int W0, int H1, int W1, float sqrt_c) {
     const int N0 = H0 * W0, N1 = H1 * W1;
@@ -38,15 +39,15 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__res
 
     // symmetric batches are virtual (Bh = B/2 images per side): direction b >= Bh swaps the roles of
     // the two feature arrays instead of reading a concatenated copy (model/network.py:213-222)
-    const float *f0b = b < Bh ? f0 + (size_t)b * C * N0 : f1 + (size_t)(b - Bh) * C * N0;
-    const float *f1b = b < Bh ? f1 + (size_t)b * C * N1 : f0 + (size_t)(b - Bh) * C * N1;
+    const FT *f0b = b < Bh ? f0 + (size_t)b * C * N0 : f1 + (size_t)(b - Bh) * C * N0;
+    const FT *f1b = b < Bh ? f1 + (size_t)b * C * N1 : f0 + (size_t)(b - Bh) * C * N1;
 
     // B operand: this wave's 32 columns of f0, all channels, kept in registers
     float bop[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int c = 2 * s + h;
-        const float v = f0b[(size_t)min(c, C - 1) * N0 + ic];
+        const float v = (float)f0b[(size_t)min(c, C - 1) * N0 + ic];
         bop[s] = c < C ? v : 0.f;
     }
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const float *__res
         const int jl = min(j0 + col, N1 - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            a[s] = f1b[(size_t)min(2 * s + h, C - 1) * N1 + jl];  // channels >= C meet a zero in bop
+            a[s] = (float)f1b[(size_t)min(2 * s + h, C - 1) * N1 + jl];  // channels >= C meet a zero in bop
         }
     };
     float a_cur[KS], a_nxt[KS];
@@ -196,20 +197,20 @@ int check_args(const void *f0, const void *f1, int B, int C, int H0, int W0, int
     return GFN_OK;
 }
 
-template <bool WV, bool WF>
-int launch_corr(const float *f0, const float *f1, float *vol, float *flow, int B, int Bh, int C, int H0, int W0, int H1,
+template <bool WV, bool WF, typename FT>
+int launch_corr(const FT *f0, const FT *f1, float *vol, float *flow, int B, int Bh, int C, int H0, int W0, int H1,
                 int W1, hipStream_t stream) {
     const int waves = B * ((H0 * W0 + 31) / 32);
     const dim3 grid((waves + 3) / 4), block(256);
     const float sc = (float)sqrt((double)C);
     if (C <= 16)
-        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else if (C <= 32)
-        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else if (C <= 64)
-        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     else
-        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
     return gfn::check_launch("corr_softargmax_kernel");
 }
 
@@ -223,6 +224,20 @@ GFN_EXPORT int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *
         return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: symmetric needs an even batch and equal map sizes");
     if (B == 0) return GFN_OK;
     return launch_corr<false, true>(f0, f1, nullptr, flow, B, symmetric ? B / 2 : B, C, H0, W0, H1, W1, (hipStream_t)stream);
+}
+
+GFN_EXPORT int gfn_corr_softargmax_fwd_dt(const void *f0, const void *f1, int dtype, float *flow, int B, int C, int H0, int W0,
+                                          int H1, int W1, int symmetric, gfn_stream_t stream) {
+    if (dtype == GFN_F32)
+        return gfn_corr_softargmax_fwd(static_cast<const float *>(f0), static_cast<const float *>(f1), flow, B, C, H0, W0, H1, W1, symmetric, stream);
+    if (dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: feature dtype must be GFN_F32 or GFN_F16");
+    if (int e = check_args(static_cast<const float *>(f0), static_cast<const float *>(f1), B, C, H0, W0, H1, W1)) return e;
+    if (!flow) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: null flow");
+    if (symmetric && ((B & 1) || H0 != H1 || W0 != W1))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: symmetric needs an even batch and equal map sizes");
+    if (B == 0) return GFN_OK;
+    return launch_corr<false, true>(static_cast<const _Float16 *>(f0), static_cast<const _Float16 *>(f1), nullptr, flow, B, symmetric ? B / 2 : B, C,
+                                    H0, W0, H1, W1, (hipStream_t)stream);
 }
 
 GFN_EXPORT int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C,

@@ -112,7 +112,19 @@ __device__ __forceinline__ BilinP bilin_pairs(float gx, float gy, int W, int H) 
 // Symmetric batches are virtual: direction b < Bh queries image A[b] against B[b], direction
 // b >= Bh queries B[b-Bh] against A[b-Bh] (the reference concatenates the pyramids instead,
 // model/network.py:213-222).
-__global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restrict__ fa, const float *__restrict__ fb,
+// two horizontally adjacent pixels of a map stored as FT, widened to fp32: an 8-byte (fp32, 4-byte aligned) or a 4-byte (fp16,
+// 2-byte aligned) gather
+struct __attribute__((packed, aligned(2))) h16x2u { _Float16 x, y; };
+__device__ __forceinline__ f32x2u ld_pair(const float *q) { return *reinterpret_cast<const f32x2u *>(q); }
+__device__ __forceinline__ f32x2u ld_pair(const _Float16 *q) {
+    const h16x2u v = *reinterpret_cast<const h16x2u *>(q);
+    f32x2u o;
+    o.x = (float)v.x; o.y = (float)v.y;
+    return o;
+}
+
+template <typename FT>
+__global__ __launch_bounds__(256) void refiner_input_kernel(const FT *__restrict__ fa, const FT *__restrict__ fb,
                                                             const float *__restrict__ flow, const float *__restrict__ dw,
                                                             const float *__restrict__ db, float *__restrict__ d, long d_bs,
                                                             int B, int Bh, int C, int Hs, int Ws, int G, int Dd,
@@ -125,8 +137,8 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
     const unsigned cell = blockIdx.x * 256u + threadIdx.x;
     if (cell >= GG) return;
     const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
-    const float *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
-    const float *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
+    const FT *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
+    const FT *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
     const float cx = gfn::linspace_at(lo, hi, G, j), cy = gfn::linspace_at(lo, hi, G, i);  // network.py:539-546
     const float *fl = flow + (size_t)b * 2 * GG;
     const float fx = fl[cell], fy = fl[GG + cell];
@@ -138,11 +150,11 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
             f32x2u va[8][2], vb[8][2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
+                const FT *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    va[k][e] = *reinterpret_cast<const f32x2u *>(qp + sa.o[e]);
-                    vb[k][e] = *reinterpret_cast<const f32x2u *>(sp + sb.o[e]);
+                    va[k][e] = ld_pair(qp + sa.o[e]);
+                    vb[k][e] = ld_pair(sp + sb.o[e]);
                 }
             }
 #pragma unroll
@@ -168,8 +180,8 @@ __global__ __launch_bounds__(256) void refiner_input_kernel(const float *__restr
             float ra = 0.f, rb = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                ra += (q + (size_t)c * plane)[sa.o[e]] * sa.w[e];
-                rb += (sm + (size_t)c * plane)[sb.o[e]] * sb.w[e];
+                ra += (float)(q + (size_t)c * plane)[sa.o[e]] * sa.w[e];
+                rb += (float)(sm + (size_t)c * plane)[sb.o[e]] * sb.w[e];
             }
             (o + (size_t)c * GG)[cell] = ra;
             (o + (size_t)(C + c) * GG)[cell] = rb;
@@ -391,6 +403,13 @@ inline unsigned grid_for(long total, int cap = 16384) {
 GFN_EXPORT int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w,
                                      const float *disp_b, float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G,
                                      int disp_dim, float disp_scale, int symmetric, gfn_stream_t stream) {
+    return gfn_refiner_input_fwd_dt(f0, f1, GFN_F32, flow, disp_w, disp_b, d, d_bs, B, C, Hs, Ws, G, disp_dim, disp_scale, symmetric, stream);
+}
+
+GFN_EXPORT int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtype, const float *flow, const float *disp_w,
+                                        const float *disp_b, float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G,
+                                        int disp_dim, float disp_scale, int symmetric, gfn_stream_t stream) {
+    if (dtype != GFN_F32 && dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: feature dtype must be GFN_F32 or GFN_F16");
     if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b)))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: null pointer");
     if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G ||
@@ -398,8 +417,15 @@ GFN_EXPORT int gfn_refiner_input_fwd(const float *f0, const float *f1, const flo
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
     if (B == 0) return GFN_OK;
     if (B > 65535 || (long)G * G >= (1L << 31)) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: batch > 65535 or grid too large");
-    hipLaunchKernelGGL(refiner_input_kernel, dim3((unsigned)(((long)G * G + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, flow, disp_w,
-                       disp_b, d, (long)d_bs, B, symmetric ? B / 2 : B, C, Hs, Ws, G, disp_dim, disp_scale);
+    const dim3 grid((unsigned)(((long)G * G + 255) / 256), (unsigned)B);
+    if (dtype == GFN_F16)
+        hipLaunchKernelGGL(refiner_input_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const _Float16 *>(f0),
+                           static_cast<const _Float16 *>(f1), flow, disp_w, disp_b, d, (long)d_bs, B, symmetric ? B / 2 : B, C, Hs, Ws, G, disp_dim,
+                           disp_scale);
+    else
+        hipLaunchKernelGGL(refiner_input_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const float *>(f0),
+                           static_cast<const float *>(f1), flow, disp_w, disp_b, d, (long)d_bs, B, symmetric ? B / 2 : B, C, Hs, Ws, G, disp_dim,
+                           disp_scale);
     return gfn::check_launch("refiner_input_kernel");
 }
 

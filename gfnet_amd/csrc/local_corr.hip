@@ -53,8 +53,9 @@ constexpr int kTodoHdr = 8;               // ints in front of the tile list in s
 
 struct LcParams {
     const float *f0;
-    const float *f1;
-    const float *f1_second;  // symmetric batches: f1 of directions b >= Bh (NULL: f1 holds all B maps)
+    const void *f1;          // feature maps (B or Bh, C, H, W), fp32 or fp16 (f16 != 0): BASELINE config 5 stores the pyramids in fp16
+    const void *f1_second;   // symmetric batches: f1 of directions b >= Bh (NULL: f1 holds all B maps)
+    int f16;
     int Bh;
     const float *flow;
     float *out;
@@ -84,10 +85,14 @@ struct LcParams {
 
 // f1 map of direction b.  Symmetric batches are virtual: the second half of the directions reads
 // the other image's features (f1_second) instead of a concatenated copy (model/network.py:213-222).
-__device__ __forceinline__ const float *f1_of(const LcParams &p, int b) {
+template <typename FT>
+__device__ __forceinline__ const FT *f1_of(const LcParams &p, int b) {
     const size_t chw = (size_t)p.C * p.H * p.W;
-    return (b < p.Bh) ? p.f1 + (size_t)b * chw : p.f1_second + (size_t)(b - p.Bh) * chw;
+    return (b < p.Bh) ? static_cast<const FT *>(p.f1) + (size_t)b * chw : static_cast<const FT *>(p.f1_second) + (size_t)(b - p.Bh) * chw;
 }
+// a feature value as fp32 (fp16 storage is widened in registers; every sum stays fp32)
+__device__ __forceinline__ float ldf(const float *q) { return *q; }
+__device__ __forceinline__ float ldf(const _Float16 *q) { return (float)*q; }
 
 struct Region {
     int x0, y0, w, h, pitch;
@@ -121,6 +126,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * (float)size - 1.f) / 2.f; }
 
 // ---- general per-tap evaluation (mirrors the reference op for op) ---------------------------
+template <typename FT>
 __device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, int j, int ky, int kx, int D, float nx, float ny) {
     float ylo, yhi, xlo, xhi;
     if (p.grid_based) {
@@ -141,7 +147,7 @@ __device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, in
     const bool xa = (unsigned)x0 < (unsigned)p.W, xb = (unsigned)(x0 + 1) < (unsigned)p.W;
     const bool ya = (unsigned)y0 < (unsigned)p.H, yb = (unsigned)(y0 + 1) < (unsigned)p.H;
     const float *f0p = p.f0 + (size_t)b * p.f0_bs + (size_t)i * p.G + j;
-    const float *f1p = f1_of(p, b);
+    const FT *f1p = f1_of<FT>(p, b);
     const size_t plane = (size_t)p.H * p.W, cs = (size_t)p.G * p.G;
     const long o00 = (long)y0 * p.W + x0;
     // zero padding without branches: a corner outside the image reads pixel 0 with weight 0 (adds an exact 0), so the
@@ -155,8 +161,8 @@ __device__ __forceinline__ float tap_general(const LcParams &p, int b, int i, in
 #pragma unroll
         for (int u = 0; u < UC; ++u) {
             const int c = min(c0 + u, p.C - 1);
-            const float *pl = f1p + c * plane;
-            va[u] = pl[oa]; vb[u] = pl[ob]; vc[u] = pl[oc]; vd[u] = pl[od];
+            const FT *pl = f1p + c * plane;
+            va[u] = ldf(pl + oa); vb[u] = ldf(pl + ob); vc[u] = ldf(pl + oc); vd[u] = ldf(pl + od);
             q[u] = f0p[c * cs];
         }
 #pragma unroll
@@ -184,6 +190,7 @@ __device__ __forceinline__ void cell_coords(const LcParams &p, int b, int i, int
     }
 }
 
+template <typename FT>
 __global__ __launch_bounds__(256) void local_corr_general_kernel(LcParams p) {
     const int D = 2 * p.r + 1, K = D * D;
     const long total = (long)p.B * K * p.G * p.G;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void local_corr_general_kernel(LcParams p) {
         const int b = (int)(t / K);
         float nx, ny;
         cell_coords(p, b, i, j, nx, ny);
-        p.out[(size_t)b * p.out_bs + ((size_t)k * p.G + i) * p.G + j] = tap_general(p, b, i, j, k / D, k % D, D, nx, ny);
+        p.out[(size_t)b * p.out_bs + ((size_t)k * p.G + i) * p.G + j] = tap_general<FT>(p, b, i, j, k / D, k % D, D, nx, ny);
     }
 }
 
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void local_corr_bwd_f0_kernel(LcParams p, cons
         const int c0 = cg * kBwdCh, nc = min(kBwdCh, p.C - c0);
         float nx, ny;
         cell_coords(p, b, i, j, nx, ny);
-        const float *f1p = f1_of(p, b) + (size_t)c0 * plane;
+        const float *f1p = f1_of<float>(p, b) + (size_t)c0 * plane;
         const float *g = gout + (size_t)b * gout_bs + (size_t)i * p.G + j;
         float acc[kBwdCh];
 #pragma unroll
@@ -280,8 +287,8 @@ struct StageRegs {
     int dst[N];  // float4 index in the stage, or -1
 };
 
-template <int N>
-__device__ __forceinline__ void stage_issue(StageRegs<N> &r, const float *f1c, int H, int W, const Region &rg, int wave,
+template <int N, typename FT>
+__device__ __forceinline__ void stage_issue(StageRegs<N> &r, const FT *f1c, int H, int W, const Region &rg, int wave,
                                             int lane, int wi_begin) {
     const int npx = rg.w * rg.h;
     const int nwi = ((npx + 63) >> 6) * 4;
@@ -299,10 +306,10 @@ __device__ __forceinline__ void stage_issue(StageRegs<N> &r, const float *f1c, i
         // one VGPR per address instead of a 64-bit pair
         const unsigned off = ok ? (unsigned)(cg * 4) * pl32 + (unsigned)((rg.y0 + y) * W + (rg.x0 + x)) : 0u;
         const unsigned st = ok ? pl32 : 0u;
-        r.v[u].x = f1c[off];
-        r.v[u].y = f1c[off + st];
-        r.v[u].z = f1c[off + 2 * st];
-        r.v[u].w = f1c[off + 3 * st];
+        r.v[u].x = ldf(f1c + off);
+        r.v[u].y = ldf(f1c + (off + st));
+        r.v[u].z = ldf(f1c + (off + 2 * st));
+        r.v[u].w = ldf(f1c + (off + 3 * st));
         r.dst[u] = ok ? (y * rg.pitch + x) * kSlotV4 + cg : -1;
     }
 }
@@ -315,8 +322,8 @@ __device__ __forceinline__ void stage_commit(float4 *s4, const StageRegs<N> &r) 
 }
 
 // whatever of the region the first `done` wave-iterations per wave did not cover
-template <int N>
-__device__ __forceinline__ void stage_rest(float4 *s4, const float *f1c, int H, int W, const Region &rg, int wave, int lane,
+template <int N, typename FT>
+__device__ __forceinline__ void stage_rest(float4 *s4, const FT *f1c, int H, int W, const Region &rg, int wave, int lane,
                                            int done) {
     const int nwi = ((rg.w * rg.h + 63) >> 6) * 4;
     for (int wi0 = done * kWaves; wi0 < nwi; wi0 += kWaves * N) {
@@ -336,7 +343,7 @@ __device__ __forceinline__ void stage_rest(float4 *s4, const float *f1c, int H, 
 //   SECOND = true : second launch -- an irregular tile is cut into 4 x 8 sub-tiles, each staged on
 //                   its own (half the footprint along the grid row, so twice the magnification
 //                   fits); a sub-tile that still does not fit falls through to the gather variant.
-template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND>
+template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND, typename FT>
 __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0, int col0, int rows, unsigned wid,
                                              unsigned char *smem) {
     constexpr int PW = 2 * R + 2;            // patch width: taps -R..R plus the +1 bilinear neighbour
@@ -487,14 +494,14 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         } else {
             __syncthreads();
             if (ABL(p, 1024)) return;
-            process_tile<R, ROUNDS, false, TW, true>(p, b, row0, col0, rows, wid, smem);  // gather from L2
+            process_tile<R, ROUNDS, false, TW, true, FT>(p, b, row0, col0, rows, wid, smem);  // gather from L2
         }
         return;
     }
 
     // the first chunk's stage loads go out before the per-lane addressing below: ~2.5 k cycles of index arithmetic under the
     // round trip instead of in front of it
-    const float *f1b = f1_of(p, b);
+    const FT *f1b = f1_of<FT>(p, b);
     constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
     StageRegs<PRE> pre;
     constexpr int PRE0 = R <= 2 ? 4 : 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at
@@ -570,7 +577,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     if (STAGED) __syncthreads();
     STAMP(4);
     for (int c0 = 0; c0 < p.C; c0 += kChunk) {
-        const float *f1c = f1b + (size_t)c0 * H * W;
+        const FT *f1c = f1b + (size_t)c0 * H * W;
         const bool more = c0 + kChunk < p.C;
         if (STAGED) {
             // keep the packed indices packed: without this the unpacking is hoisted out of the loop and
@@ -623,7 +630,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                             in[tt] = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H) & !ABL(p, 2048);
                             const unsigned off = in[tt] ? (unsigned)(Y * W + X) : 0u;  // offset 0 when outside: valid memory, masked below
 #pragma unroll
-                            for (int k = 0; k < kChunk; ++k) v[tt][k] = (f1c + k * plane)[off];  // scalar plane base + 32-bit lane offset
+                            for (int k = 0; k < kChunk; ++k) v[tt][k] = ldf(f1c + k * plane + off);  // scalar plane base + 32-bit lane offset
                         }
                     }
 #pragma unroll
@@ -739,12 +746,12 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
             const int cell = cellX0[e / K], k = e % K;
             const int gi = cell_gi(cell), gj = cell_gj(cell);
             p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
-                tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
+                tap_general<FT>(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
         }
     }
 }
 
-template <int R, int ROUNDS>
+template <int R, int ROUNDS, typename FT>
 __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef GFN_ABLATE
@@ -761,12 +768,12 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = wid / tiles, tile = wid - b * tiles;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    process_tile<R, ROUNDS, true, kTileW, false>(p, b, ty * 2 * ROUNDS, tx * kTileW, 2 * ROUNDS, wid, smem);
+    process_tile<R, ROUNDS, true, kTileW, false, FT>(p, b, ty * 2 * ROUNDS, tx * kTileW, 2 * ROUNDS, wid, smem);
 }
 
 // second launch: the tiles the staged kernel left in p.todo (their number is only known on the
 // device), re-cut into sub-tiles 8 cells wide and up to 4 rows high
-template <int R, int ROUNDS>
+template <int R, int ROUNDS, typename FT>
 __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 2 * ROUNDS, SH = TH < 4 ? TH : 4;  // sub-tile height
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
         const int sub = it % SUBS;
         const int b = wid / tiles, tile = wid - b * tiles;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-        process_tile<R, 1, true, 8, true>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
+        process_tile<R, 1, true, 8, true, FT>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
         __syncthreads();  // LDS (and next_item) are reused by the next sub-tile
         if (threadIdx.x == 0) next_item = part + atomicAdd(p.todo + 1, 1);
         __syncthreads();
@@ -808,10 +815,10 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 
 #include "local_corr_lean.h"
 
-template <int R, int NCH>
+template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH>), dim3(total), dim3(kThreads), lds, stream, p);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total), dim3(kThreads), lds, stream, p);
 }
 
 // compute units of the current device (queried once per device: hipGetDeviceProperties is slow)
@@ -827,7 +834,7 @@ int device_cu_count() {
     return cache[dev];
 }
 
-template <int R, int ROUNDS>
+template <int R, int ROUNDS, typename FT>
 int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
@@ -847,9 +854,9 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     // one workgroup per CU; absurdly wide features go to the general kernel
     if (lds > kMaxLds) return -1000;
     // per call and unconditional: the attribute is per device, a process may drive several
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS, FT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS, FT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
@@ -859,19 +866,19 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
             hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
             if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
             switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-                case 16: launch_lean<R, 1>(p, total, lds2, stream); break;
-                case 32: launch_lean<R, 2>(p, total, lds2, stream); break;
-                default: launch_lean<R, 4>(p, total, lds2, stream); break;
+                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
+                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
+                default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
             }
             if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
         }
     }
     if (!(lean && ROUNDS == 2)) {
-        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS>), dim3(total), dim3(kThreads), lds, stream, p);
+        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
         if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
     }
     const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
-    hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS>), dim3(grid2), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
     return gfn::check_launch("local_corr_irregular_kernel");
 }
 
@@ -889,6 +896,15 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
                                      const float *flow, float *out, int64_t out_bs, int B, int C, int G, int H, int W,
                                      int r, int grid_based, int win_h, int win_w, int variant, void *scratch,
                                      int64_t scratch_bytes, gfn_stream_t stream) {
+    return gfn_local_corr_fwd_dt(f0, f0_bs, f1, f1_second, GFN_F32, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, variant, scratch,
+                                 scratch_bytes, stream);
+}
+
+GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void *f1, const void *f1_second, int f1_dtype,
+                                     const float *flow, float *out, int64_t out_bs, int B, int C, int G, int H, int W,
+                                     int r, int grid_based, int win_h, int win_w, int variant, void *scratch,
+                                     int64_t scratch_bytes, gfn_stream_t stream) {
+    if (f1_dtype != GFN_F32 && f1_dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: feature dtype must be GFN_F32 or GFN_F16");
     if (!f0 || !f1 || !out) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: null tensor pointer");
     if (f1_second && (B & 1)) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: symmetric batch must be even");
     if (B < 0 || C <= 0 || G <= 0 || H <= 0 || W <= 0 || r < 0 || win_h <= 0 || win_w <= 0)
@@ -906,6 +922,7 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     LcParams p;
     p.f0 = f0; p.f1 = f1; p.flow = flow; p.out = out;
     p.f1_second = f1_second;
+    p.f16 = f1_dtype == GFN_F16;
     p.Bh = f1_second ? B / 2 : B;
     p.f0_bs = f0_bs; p.out_bs = out_bs;
     p.B = B; p.C = C; p.G = G; p.H = H; p.W = W;
@@ -925,7 +942,7 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
     // variant 0: the tiled path (lean tile kernel for r <= 4); 1: general kernel; 2: the round-1 tile kernel for every radius
     // (kept as the bit-exact cross-check of the lean kernel)
     // the lean path keeps at most 8 channels of the f0 block per wave in registers and addresses planes with 32-bit byte offsets
-    bool lean = variant == 0 && flow && (C == 16 || C == 32 || C == 64) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
+    bool lean = variant == 0 && flow && (C == 16 || C == 32 || C == 64) && !(p.f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
     if (lean && scratch) {
         const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
         const uintptr_t pl = ((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 31) & ~(uintptr_t)31;
@@ -936,20 +953,33 @@ GFN_EXPORT int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float
                          scratch && scratch_bytes >= gfn_local_corr_scratch_bytes(B, G) && ((uintptr_t)scratch & 3) == 0;
     if (fast_ok) {
         int rc = -1000;
-        switch (r) {
-            case 1: rc = launch_tile<1, 2>(p, s, lean); break;
-            case 2: rc = launch_tile<2, 2>(p, s, lean); break;
-            case 3: rc = launch_tile<3, 2>(p, s, lean); break;
-            case 4: rc = launch_tile<4, 2>(p, s, lean); break;
-            case 5: rc = launch_tile<5, 1>(p, s, lean); break;
-            case 6: rc = launch_tile<6, 1>(p, s, lean); break;
-            case 7: rc = launch_tile<7, 1>(p, s, lean); break;
+        if (p.f16) {
+            switch (r) {
+                case 1: rc = launch_tile<1, 2, _Float16>(p, s, lean); break;
+                case 2: rc = launch_tile<2, 2, _Float16>(p, s, lean); break;
+                case 3: rc = launch_tile<3, 2, _Float16>(p, s, lean); break;
+                case 4: rc = launch_tile<4, 2, _Float16>(p, s, lean); break;
+                case 5: rc = launch_tile<5, 1, _Float16>(p, s, lean); break;
+                case 6: rc = launch_tile<6, 1, _Float16>(p, s, lean); break;
+                case 7: rc = launch_tile<7, 1, _Float16>(p, s, lean); break;
+            }
+        } else {
+            switch (r) {
+                case 1: rc = launch_tile<1, 2, float>(p, s, lean); break;
+                case 2: rc = launch_tile<2, 2, float>(p, s, lean); break;
+                case 3: rc = launch_tile<3, 2, float>(p, s, lean); break;
+                case 4: rc = launch_tile<4, 2, float>(p, s, lean); break;
+                case 5: rc = launch_tile<5, 1, float>(p, s, lean); break;
+                case 6: rc = launch_tile<6, 1, float>(p, s, lean); break;
+                case 7: rc = launch_tile<7, 1, float>(p, s, lean); break;
+            }
         }
         if (rc != -1000) return rc;  // -1000: shape not supported by the tiled path
     }
     const long total = (long)B * K * G * G;
     const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(local_corr_general_kernel, dim3(grid), dim3(256), 0, s, p);
+    if (p.f16) hipLaunchKernelGGL(local_corr_general_kernel<_Float16>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(local_corr_general_kernel<float>, dim3(grid), dim3(256), 0, s, p);
     return gfn::check_launch("local_corr_general_kernel");
 }
 
@@ -977,6 +1007,7 @@ GFN_EXPORT int gfn_local_corr_bwd_f0(const float *grad_out, int64_t grad_out_bs,
     if (B == 0) return GFN_OK;
     LcParams p{};
     p.f1 = f1; p.f1_second = f1_second; p.flow = flow;
+    p.f16 = 0;
     p.Bh = f1_second ? B / 2 : B;
     p.B = B; p.C = C; p.G = G; p.H = H; p.W = W;
     p.sqrt_c = (float)sqrt((double)C);

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
                 // returns zeros, and is masked per pixel).  Interior tiles: the same alignment makes the quads 16-byte
                 // aligned when rows are multiples of 4 pixels; taken where it is free, i.e. does not add a quad per row (an
                 // extra quad pushes the row pitch to the next conflict-free value or the region out of the stage).
-                u.x0 = bx0;
+                // fp16 maps: a quad is 8 bytes and buffer loads want 4-byte alignment, so the region starts on an even pixel
+                // (rows are an even number of pixels there: the host sends odd row lengths to the round-1 path).
+                u.x0 = p.f16 ? (bx0 & ~1) : bx0;
                 {
                     const int xa = bx0 & ~3;
                     if (!all_in || ((p.W & 3) == 0 && ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2))) u.x0 = xa;
@@ -198,6 +200,27 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) 
 __device__ __forceinline__ f32x4 buf_ld4(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 buf_ld_h4(rsrc_t r, unsigned voff, unsigned soff) {
+    // the builtin's result is bit-cast as a whole: picking the two dwords apart (.x / .y of a 2-vector) made hipcc 7.2 narrow the
+    // load to one dword and reuse it for both halves
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+// a quad of 4 pixels of one channel plane as it comes from memory, and widened to fp32
+template <typename FT> struct QuadRaw;
+template <> struct QuadRaw<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ type load(rsrc_t r, unsigned voff, unsigned soff) { return buf_ld4(r, voff, soff); }
+    static __device__ __forceinline__ f32x4 widen(type v) { return v; }
+};
+template <> struct QuadRaw<_Float16> {
+    typedef f16x4 type;
+    static __device__ __forceinline__ type load(rsrc_t r, unsigned voff, unsigned soff) { return buf_ld_h4(r, voff, soff); }
+    static __device__ __forceinline__ f32x4 widen(type v) {
+        f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        return o;
+    }
+};
 __device__ __forceinline__ void buf_st_nt(rsrc_t r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 2);  // 2 = nt (streaming store)
 }
@@ -206,22 +229,23 @@ __device__ __forceinline__ void buf_st_nt(rsrc_t r, unsigned voff, unsigned soff
 // Work item it (of a 16-channel chunk) = (row group it >> 2, channel quad it & 3); wave w takes items w, w + 8, ...  A lane
 // owns quad `q` of region row `rg * rpi + ry` (ry = lane / nq, q = lane % nq): four loads (one per channel plane of the
 // quad) bring 4 pixels x 4 channels, which leave as four 16-byte slot writes (pixel-major [pixel][16 channels + pad]).
-template <int N>
+template <int N, typename FT>
 struct QuadRegs {
-    f32x4 a[N][4];  // [item][channel of the quad] -> 4 pixels
+    typename QuadRaw<FT>::type a[N][4];  // [item][channel of the quad] -> 4 pixels, as loaded (fp16 is widened at the commit)
 };
 
 struct QuadLane {         // per lane, constant for the tile
-    unsigned voff;        // byte offset of the lane's quad inside an image plane, relative to the region's first row group
+    unsigned voff;        // byte offset (in the map's storage type) of the lane's quad inside an image plane, relative to the region's first row group
     int slot;             // float4 index of the lane's first pixel slot, relative to the row group and channel quad
     int ry;               // region row inside a row group (>= rpi: lane idle)
     unsigned xmask;       // CHECK: bit k set = pixel k of the quad lies inside the image
 };
 
-template <int N, bool CHECK>
-__device__ __forceinline__ void quad_issue(QuadRegs<N> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
+template <int N, bool CHECK, typename FT>
+__device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
                                            const QuadLane &ql, int k0) {
-    const unsigned plane4 = (unsigned)(H * W) * 4u;
+    constexpr unsigned ES = sizeof(FT);
+    const unsigned plane4 = (unsigned)(H * W) * ES;  // bytes of a channel plane
     const int ipw = u.nitems >> 3;  // items per wave
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -230,21 +254,21 @@ __device__ __forceinline__ void quad_issue(QuadRegs<N> &r, rsrc_t f1r, unsigned 
         const int cg = it & 3, row0 = (it >> 2) * u.rpi;          // scalars
         unsigned so = chunk_off + (unsigned)cg * 4u * plane4, vo;
         if (!CHECK) {
-            so += (unsigned)((u.y0 + row0) * W) * 4u;             // every staged row lies inside the image
+            so += (unsigned)((u.y0 + row0) * W) * ES;             // every staged row lies inside the image
             vo = ql.voff;
         } else {
             // rows may lie outside the image (then the scalar row offset could be negative): the row goes into the
             // per-lane offset, lanes of outside rows point at pixel 0 and are zeroed at the commit
             const int gy = u.y0 + row0 + ql.ry;
-            vo = (unsigned)gy < (unsigned)H ? ql.voff + (unsigned)((u.y0 + row0) * W) * 4u : 0u;
+            vo = (unsigned)gy < (unsigned)H ? ql.voff + (unsigned)((u.y0 + row0) * W) * ES : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.a[n][j] = buf_ld4(f1r, vo, so + (unsigned)j * plane4);
+        for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
     }
 }
 
-template <int N, bool CHECK>
-__device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N> &r, int H, const RowPlan &u, int wave, const QuadLane &ql, int k0) {
+template <int N, bool CHECK, typename FT>
+__device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r, int H, const RowPlan &u, int wave, const QuadLane &ql, int k0) {
     const int ipw = u.nitems >> 3;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -254,9 +278,11 @@ __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N> &r, in
             float4 *dst = s4 + (ql.slot + row0 * u.pitch) * kSlotV4 + cg;
             unsigned m = 0xFu;
             if (CHECK) m = (unsigned)(u.y0 + row0 + ql.ry) < (unsigned)H ? ql.xmask : 0u;
+            const f32x4 w0 = QuadRaw<FT>::widen(r.a[n][0]), w1 = QuadRaw<FT>::widen(r.a[n][1]), w2 = QuadRaw<FT>::widen(r.a[n][2]),
+                        w3 = QuadRaw<FT>::widen(r.a[n][3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float4 v = make_float4(r.a[n][0][k], r.a[n][1][k], r.a[n][2][k], r.a[n][3][k]);
+                float4 v = make_float4(w0[k], w1[k], w2[k], w3[k]);
                 if (CHECK && !((m >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[k * kSlotV4] = v;
             }
@@ -264,13 +290,13 @@ __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N> &r, in
     }
 }
 
-template <bool CHECK>
+template <bool CHECK, typename FT>
 __device__ __forceinline__ void quad_rest(float4 *s4, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
                                           const QuadLane &ql, int done) {
     for (int k0 = done; k0 < (u.nitems >> 3); ++k0) {  // only regions taller than two row groups per wave pair (rare)
-        QuadRegs<1> r;
-        quad_issue<1, CHECK>(r, f1r, chunk_off, H, W, u, wave, ql, k0);
-        quad_commit<1, CHECK>(s4, r, H, u, wave, ql, k0);
+        QuadRegs<1, FT> r;
+        quad_issue<1, CHECK, FT>(r, f1r, chunk_off, H, W, u, wave, ql, k0);
+        quad_commit<1, CHECK, FT>(s4, r, H, u, wave, ql, k0);
     }
 }
 
@@ -293,7 +319,7 @@ struct DivPW {
 // falls back to vmcnt(0) and the cell set-up ends up waiting for the stage loads issued after it.
 // HALVES: the tile is staged as two 4 x 8-cell halves, one after the other (region uA for cells 0-31 = round 0, uB for cells
 // 32-63 = round 1); otherwise uA serves both rounds.
-template <int R, int NCH, bool CHECK, bool HALVES>
+template <int R, int NCH, bool CHECK, bool HALVES, typename FT>
 __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, unsigned wid, int tid,
                                           int lane, int wave) {
     constexpr int ROUNDS = 2;
@@ -366,14 +392,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int k = 0; k < 4; ++k) ql.xmask |= ((unsigned)(u.x0 + 4 * q + k) < (unsigned)W ? 1u : 0u) << k;
         // border tiles: x0 is a multiple of 4 (plan launch), so a quad never straddles the left image edge; quads left of the
         // image point at column 0 and are zeroed by the mask, like the pixels of a quad that hangs over the right edge
-        ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * 4u;
+        ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * (unsigned)sizeof(FT);
         return ql;
     };
     const QuadLane qlA = quad_lane(uA);
-    const rsrc_t f1r = make_rsrc(f1_of(p, b), (unsigned)C * (unsigned)(H * W) * 4u);
+    const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
     constexpr int PRE = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
-    QuadRegs<PRE> pre;
-    quad_issue<PRE, CHECK>(pre, f1r, 0u, H, W, uA, wave, qlA, 0);
+    QuadRegs<PRE, FT> pre;
+    quad_issue<PRE, CHECK, FT>(pre, f1r, 0u, H, W, uA, wave, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
@@ -413,8 +439,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int k = 0; k < NF0; ++k) f0s[fcell * CS + wave + k * kWaves] = fok ? f0v[k] : 0.f;
     }
     STAMP(2);
-    quad_commit<PRE, CHECK>(s4, pre, H, uA, wave, qlA, 0);
-    quad_rest<CHECK>(s4, f1r, 0u, H, W, uA, wave, qlA, PRE);
+    quad_commit<PRE, CHECK, FT>(s4, pre, H, uA, wave, qlA, 0);
+    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, qlA, PRE);
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -458,14 +484,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const int c0 = ch * kChunk;
         const bool more = st + 1 < NS;
         const int nch = HALVES ? (st + 1) % NCH : st + 1, nhalf = HALVES ? (st + 1) / NCH : 0;
-        const unsigned next_off = (unsigned)(nch * kChunk) * (unsigned)(H * W) * 4u;  // byte offset of the next step's first plane
+        const unsigned next_off = (unsigned)(nch * kChunk) * (unsigned)(H * W) * (unsigned)sizeof(FT);  // byte offset of the next step's first plane
         const RowPlan &un = (HALVES && nhalf == 1) ? uB : uA;
         const QuadLane &qn = (HALVES && nhalf == 1) ? qlB : qlA;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) quad_issue<PRE, CHECK>(pre, f1r, next_off, H, W, un, wave, qn, 0);  // next step's loads: in flight across this D-stage
+        if (more) quad_issue<PRE, CHECK, FT>(pre, f1r, next_off, H, W, un, wave, qn, 0);  // next step's loads: in flight across this D-stage
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
@@ -497,8 +523,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (more) {
             __syncthreads();  // everyone is done reading this step's pixels
             STAMP(7);
-            quad_commit<PRE, CHECK>(s4, pre, H, un, wave, qn, 0);
-            quad_rest<CHECK>(s4, f1r, next_off, H, W, un, wave, qn, PRE);
+            quad_commit<PRE, CHECK, FT>(s4, pre, H, un, wave, qn, 0);
+            quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, qn, PRE);
             __syncthreads();
             STAMP(8);
         }
@@ -583,12 +609,12 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             const int cell = cellX0[e / K], k = e % K;
             const int gi = row0 + cell_row(cell), gj = col0 + cell_col(cell);
             p.out[(size_t)b * p.out_bs + ((size_t)k * G + gi) * G + gj] =
-                tap_general(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
+                tap_general<FT>(p, b, gi, gj, k / D, k % D, D, cellNx[cell], cellNy[cell]);
         }
     }
 }
 
-template <int R, int NCH>
+template <int R, int NCH, typename FT>
 __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -611,10 +637,10 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     (void)region_fits<R>(uB);
     const bool interior = (flags & kPlanInterior) != 0;
     if (flags & kPlanHalves) {
-        if (interior) lean_tile<R, NCH, false, true>(p, smem, uA, uB, wid, tid, lane, wave);
-        else lean_tile<R, NCH, true, true>(p, smem, uA, uB, wid, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, wid, tid, lane, wave);
+        else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, wid, tid, lane, wave);
     } else {
-        if (interior) lean_tile<R, NCH, false, false>(p, smem, uA, uB, wid, tid, lane, wave);
-        else lean_tile<R, NCH, true, false>(p, smem, uA, uB, wid, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, wid, tid, lane, wave);
+        else lean_tile<R, NCH, true, false, FT>(p, smem, uA, uB, wid, tid, lane, wave);
     }
 }

@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import c_vp, check, f32c, ptr, require_gpu, stream_ptr
+from ._lib import c_vp, check, f32c, featc, ptr, require_gpu, stream_ptr
 
 
 def _L():
@@ -22,8 +22,8 @@ kernel_events = None
 # bench.py / tools set this to a dict to collect, per local-correlation call (name -> [(tiles left to the second launch,
 # cells redone per tap, tiles staged in halves), ...]), the counters the kernels leave in the scratch header; costs a device sync per call.
 kernel_counters = None
-# True once the kernels read fp16 feature maps directly (BASELINE config 5); until then fp16 inputs are widened by a cast
-NATIVE_FP16 = False
+# the kernels read fp16 feature maps directly (BASELINE config 5): no widened copy is made
+NATIVE_FP16 = True
 
 
 def _timed(name, launch):
@@ -43,15 +43,17 @@ def corr_softargmax(feat0, feat1, symmetric=False):
     directions, (feat0 vs feat1) then (feat1 vs feat0) -- the reference's concatenated batch
     (network.py:213-222) without copying the features."""
     dev = require_gpu(feat0, feat1)
-    f0, f1 = f32c(feat0), f32c(feat1)
+    (f0, dt0), (f1, dt1) = featc(feat0), featc(feat1)
+    if dt0 != dt1:
+        f0, f1, dt0 = f32c(f0), f32c(f1), _lib.GFN_F32
     B, C, H0, W0 = f0.shape
     B1, C1, H1, W1 = f1.shape
     if B1 != B or C1 != C:
         raise ValueError("feat0/feat1 batch or channel mismatch")
     nb = 2 * B if symmetric else B
     flow = torch.empty((nb, 2, H0, W0), device=dev, dtype=torch.float32)
-    check(_L().gfn_corr_softargmax_fwd(ptr(f0), ptr(f1), ptr(flow), nb, C, H0, W0, H1, W1, 1 if symmetric else 0,
-                                       stream_ptr(dev)), "gfn_corr_softargmax_fwd")
+    check(_L().gfn_corr_softargmax_fwd_dt(ptr(f0), ptr(f1), dt0, ptr(flow), nb, C, H0, W0, H1, W1, 1 if symmetric else 0,
+                                          stream_ptr(dev)), "gfn_corr_softargmax_fwd")
     return flow
 
 
@@ -84,7 +86,9 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     local_correlation(...)) -- every slice written in place by the HIP kernels, no torch.cat.
     If flow has twice the batch of x/y the call is symmetric: directions (x vs y) then (y vs x)."""
     dev = require_gpu(x, y, flow, disp_w, disp_b)
-    x, y, fl = f32c(x), f32c(y), f32c(flow)
+    (x, dtx), (y, dty), fl = featc(x), featc(y), f32c(flow)
+    if dtx != dty:
+        x, y, dtx = f32c(x), f32c(y), _lib.GFN_F32
     Bi, C, Hs, Ws = x.shape
     G = int(num_grid)
     B = fl.shape[0]
@@ -99,16 +103,16 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     CH = 2 * C + Dd + K
     d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
     st = stream_ptr(dev)
-    check(_L().gfn_refiner_input_fwd(ptr(x), ptr(y), ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
-                                     float(40 / 32 * scale_factor), 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
+    check(_L().gfn_refiner_input_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
+                                        float(40 / 32 * scale_factor), 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
     if corr_in_other:
         out = d[:, 2 * C + Dd:]
         nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
         scr = _lib.scratch(dev, nscr)
         name = f"local_corr_c{C}_h{Hs}_g{G}_r{r}"
-        check(_timed(name, lambda: _L().gfn_local_corr_fwd(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, ptr(fl),
-                                                           c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws,
-                                                           ptr(scr), nscr, st)), "gfn_local_corr_fwd")
+        check(_timed(name, lambda: _L().gfn_local_corr_fwd_dt(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, dtx, ptr(fl),
+                                                              c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws, 0,
+                                                              ptr(scr), nscr, st)), "gfn_local_corr_fwd")
         if kernel_counters is not None:
             hdr = scr[:8].cpu()  # synchronises; header layout: csrc/local_corr.hip kTodoHdr
             kernel_counters.setdefault(name, []).append((int(hdr[3]), int(hdr[5]), int(hdr[7])))

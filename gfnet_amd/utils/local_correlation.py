@@ -58,7 +58,7 @@ def _forward(featuremap_size, feature0, feature1, local_radius, num_grid, paddin
     if flow is None and not (G == h == w):
         raise ValueError("flow=None assumes aligned maps: num_grid == h == w")
     f0, f0_bs = _channel_stride_view(feature0.detach())
-    f1 = _lib.f32c(feature1.detach())
+    f1, f1_dt = _lib.featc(feature1.detach())  # fp16 maps are read as stored
     fl = _lib.f32c(flow.detach()) if flow is not None else None
     ret_dtype = feature0.dtype
     if out is None:
@@ -77,10 +77,12 @@ def _forward(featuremap_size, feature0, feature1, local_radius, num_grid, paddin
     hh, ww = h, w
     for level in range(int(num_level)):
         o = res[:, level * K1:(level + 1) * K1]
-        _lib.check(L.gfn_local_corr_fwd_ex(_lib.ptr(f0), f0_bs, _lib.ptr(f1), None, _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
+        _lib.check(L.gfn_local_corr_fwd_dt(_lib.ptr(f0), f0_bs, _lib.ptr(f1), None, f1_dt, _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
                                            out_bs, B, c, G, hh, ww, r, 1 if grid_based_correlation else 0, h, w,
                                            int(_variant), _lib.ptr(scr), nscr, st), "gfn_local_corr_fwd")
         if level + 1 < num_level:
+            if f1_dt != _lib.GFN_F32:  # pooled levels (unused by GFNet) are built in fp32
+                f1, f1_dt = _lib.f32c(f1), _lib.GFN_F32
             pooled = torch.empty((B, c, hh // 2, ww // 2), device=dev, dtype=torch.float32)
             _lib.check(L.gfn_avg_pool2(_lib.ptr(f1), _lib.ptr(pooled), B * c, hh, ww, st), "gfn_avg_pool2")
             f1, hh, ww = pooled, hh // 2, ww // 2

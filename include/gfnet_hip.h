@@ -33,6 +33,11 @@ extern "C" {
 
 #define GFN_ABI_VERSION 1
 
+/* storage type of the feature pyramids (BASELINE config 5 keeps them in fp16; reference: model/network.py:171-173 runs the
+ * backbone under autocast, utils/utils.py:306-320).  Arithmetic and every other tensor stay fp32. */
+#define GFN_F32 0
+#define GFN_F16 1
+
 typedef void *gfn_stream_t; /* hipStream_t */
 
 /* Library / device introspection.  gfn_device_arch() copies the gcnArchName of the current
@@ -75,9 +80,19 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
                        float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                        int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
-/* Variant selector for experiments/tests: 0 = auto (as above), 1 = force the general per-tap
- * kernel.  Same arguments otherwise. */
+/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4, the
+ * round-1 tile kernel above), 1 = force the general per-tap kernel, 2 = the round-1 tile kernel for every radius (the
+ * bit-exact cross-check of the lean path).  Same arguments otherwise.
+ * Scratch header (ints): [0] tiles left to the second launch, [1..2] its queue counters, [3] last call's [0], [4] cells redone
+ * per tap, [5] last call's [4], [6] tiles staged as two halves (sampled), [7] last call's [6]; [0..2], [4], [6] are zero
+ * between calls. */
 int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second, const float *flow,
+                          float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
+                          int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
+
+/* The same with the feature map f1 (and f1_second) stored as f1_dtype = GFN_F32 or GFN_F16 (read directly, widened in
+ * registers; f0, flow and out stay fp32). */
+int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void *f1, const void *f1_second, int f1_dtype, const float *flow,
                           float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                           int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
@@ -107,6 +122,9 @@ int gfn_avg_pool2(const float *in, float *out, int BC, int H, int W, gfn_stream_
  */
 int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B, int C, int H0, int W0, int H1, int W1,
                             int symmetric, gfn_stream_t stream);
+/* The same with the feature maps stored as dtype = GFN_F32 or GFN_F16 (widened on load; products and sums fp32). */
+int gfn_corr_softargmax_fwd_dt(const void *f0, const void *f1, int dtype, float *flow, int B, int C, int H0, int W0, int H1, int W1,
+                               int symmetric, gfn_stream_t stream);
 int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C, int H0, int W0,
                         int H1, int W1, gfn_stream_t stream);
 int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1, gfn_stream_t stream);
@@ -126,6 +144,10 @@ int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int 
 int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w, const float *disp_b,
                           float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
                           int symmetric, gfn_stream_t stream);
+/* The same with the two feature maps stored as dtype = GFN_F32 or GFN_F16 (gathered directly, widened in registers; d is fp32). */
+int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtype, const float *flow, const float *disp_w, const float *disp_b,
+                             float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
+                             int symmetric, gfn_stream_t stream);
 
 /* F.grid_sample(in, grid, mode='bilinear', padding_mode='zeros', align_corners=False):
  * in (B,C,H,W), grid (B,Ho,Wo,2) -> out (B,C,Ho,Wo) with batch stride out_bs. */

@@ -141,3 +141,56 @@ def test_grid_ops_on_the_672_and_224_grids(G, S):
     wo, co_ = oracle.match_post(rf, rc, c16, symmetric=True, attenuate_cert=True)
     assert_close(host(warp), wo, 1e-5, "match_post warp")
     assert_close(host(cc), co_, 1e-5, "match_post certainty")
+
+
+# ---- configs[4]: feature pyramids stored in fp16 are read as stored (no widened copy) ------------------------------------
+@pytest.mark.parametrize("c,hs,G,r,kind", [(32, 112, 64, 4, "bench"), (16, 224, 128, 2, "bench"), (64, 56, 32, 6, "bench"), (64, 32, 32, 7, "random"),
+                                           (32, 70, 40, 4, "bench"), (16, 60, 40, 3, "random"), (8, 20, 12, 2, "bench"), (32, 168, 96, 4, "zoom")])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_fp16_feature_maps_are_read_natively_and_match_the_widened_copy(c, hs, G, r, kind, variant):
+    """All arithmetic stays fp32, so reading fp16 maps directly must give bit for bit what the fp32 kernels give on the
+    widened copy (lean path, round-1 tile kernel, second launch, general kernel), and that is the oracle on rounded inputs."""
+    import synth
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B = 4
+    f0 = torch.from_numpy(synth.lattice_normalish((B, c, G, G), 901)).cuda()
+    f1h = torch.from_numpy(synth.lattice_normalish((B, c, hs, hs), 902) * np.float32(1.37)).cuda().half()  # off the fp16 lattice before rounding
+    if kind == "bench":
+        flow = _bench_flows(B, G, 448, 903)
+    elif kind == "zoom":
+        flow = synth.homography_flow(B, G, 904, scale=1.6)
+    else:
+        flow = 1.2 * synth.lattice_uniform((B, 2, G, G), 905)
+    fl = torch.from_numpy(flow).cuda()
+    got = local_correlation((B, c, hs, hs), f0, f1h, r, G, flow=fl, _variant=variant)
+    ref = local_correlation((B, c, hs, hs), f0, f1h.float(), r, G, flow=fl, _variant=variant)
+    assert got.dtype == torch.float32
+    np.testing.assert_array_equal(host(got), host(ref))
+    if variant == 0:
+        want = oracle.local_correlation((B, c, hs, hs), host(f0), host(f1h), r, G, flow=flow)
+        assert_close(host(got), want, 1e-4, "fp16 f1 vs oracle on the rounded inputs")
+
+
+def test_fp16_refiner_input_and_corr_softargmax_match_the_widened_copy():
+    import synth
+    from gfnet_amd import ops
+
+    B, c, hs, G = 2, 16, 57, 24  # odd row length: 2-byte aligned pair gathers
+    x = torch.from_numpy(synth.lattice_normalish((B, c, hs, hs), 911) * np.float32(0.77)).cuda().half()
+    y = torch.from_numpy(synth.lattice_normalish((B, c, hs, hs), 912) * np.float32(0.77)).cuda().half()
+    flow = torch.from_numpy(_bench_flows(2 * B, G, 448, 913)).cuda()
+    w = torch.from_numpy(synth.lattice_uniform((6, 2), 914)).cuda()
+    bias = torch.from_numpy(synth.lattice_uniform((6,), 915)).cuda()
+    for r in (0, 2):
+        d16 = ops.refiner_input(G, x, y, flow, w, bias, r, scale_factor=1.25, corr_in_other=r > 0)
+        d32 = ops.refiner_input(G, x.float(), y.float(), flow, w, bias, r, scale_factor=1.25, corr_in_other=r > 0)
+        np.testing.assert_array_equal(host(d16), host(d32))
+    xs, ys = np.concatenate((host(x), host(y))), np.concatenate((host(y), host(x)))
+    assert_close(host(d16), oracle.refiner_input(G, xs, ys, host(flow), host(w), host(bias), 2, scale_factor=1.25), 1e-4, "refiner_input fp16")
+    f0 = torch.from_numpy(synth.lattice_normalish((3, 64, 32, 32), 921) * np.float32(0.31)).cuda().half()
+    f1 = torch.from_numpy(synth.lattice_normalish((3, 64, 32, 32), 922) * np.float32(0.31)).cuda().half()
+    for sym in (False, True):
+        a, b = ops.corr_softargmax(f0, f1, symmetric=sym), ops.corr_softargmax(f0.float(), f1.float(), symmetric=sym)
+        np.testing.assert_array_equal(host(a), host(b))
+    assert_close(host(ops.corr_softargmax(f0, f1)), oracle.corr_softargmax(host(f0), host(f1)), 1e-4, "corr_softargmax fp16")
