@@ -45,6 +45,8 @@ _SIGNATURES = {
     "gfn_convert_matches": [c_vp, c_vp, c_i64] + [c_float] * 4 + [c_vp],
     "gfn_homography_ransac": [c_vp, c_int, c_int, c_double, c_int, ctypes.c_uint64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
                               c_vp, c_i64, c_vp],
+    "gfn_homography_ransac_ex": [c_vp, c_int, c_int, c_double, c_int, c_double, ctypes.c_uint64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_i64, c_vp],
     "gfn_homography_dlt": [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
     "gfn_local_corr_bwd_f0": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 9 + [c_vp],
     "gfn_resize_normalize_fwd": [c_vp, c_i64, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp],

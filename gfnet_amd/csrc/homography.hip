@@ -36,18 +36,18 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-__device__ __forceinline__ uint32_t draw_index(uint64_t seed, uint32_t b, uint32_t t, uint32_t k, uint32_t a, uint32_t N) {
+__device__ __forceinline__ uint32_t draw_index(uint64_t seed, uint32_t b, uint32_t t, uint32_t k, uint32_t a, uint32_t s, uint32_t N) {
     uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)b << 32) | t));
-    h = splitmix64(h + ((uint64_t)k << 8) + a);
+    h = splitmix64(h + ((uint64_t)s << 16) + ((uint64_t)k << 8) + a);
     return (uint32_t)(h % N);
 }
 
-__device__ bool draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t N, uint32_t idx[4]) {
+__device__ bool draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t s, uint32_t N, uint32_t idx[4]) {
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         uint32_t a = 0;
         for (;;) {
-            const uint32_t v = draw_index(seed, b, t, k, a, N);
+            const uint32_t v = draw_index(seed, b, t, k, a, s, N);
             bool dup = false;
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) dup |= (q < k) & (idx[q] == v);
@@ -56,6 +56,84 @@ __device__ bool draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t N, u
         }
     }
     return true;
+}
+
+// HomographyEstimatorCallback::checkSubset for 4 correspondences, the operation sequence of subset_ok() in the oracle:
+// the last point must not be collinear (within rounding) with two of the first three in either image, and the four
+// triplets must keep or all flip their orientation between the images.
+__device__ bool subset_ok(const float4 *pts, const uint32_t idx[4]) {
+    double X[2][4], Y[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 p = pts[idx[k]];
+        X[0][k] = p.x; Y[0][k] = p.y; X[1][k] = p.z; Y[1][k] = p.w;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double dx1 = X[im][j] - X[im][3], dy1 = Y[im][j] - Y[im][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k >= j) continue;
+                const double dx2 = X[im][k] - X[im][3], dy2 = Y[im][k] - Y[im][3];
+                ok &= !(fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)));
+            }
+        }
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double det[2];
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const double x0 = X[im][tt[i][0]], y0 = Y[im][tt[i][0]], x1 = X[im][tt[i][1]], y1 = Y[im][tt[i][1]];
+            const double x2 = X[im][tt[i][2]], y2 = Y[im][tt[i][2]];
+            det[im] = (x0 * (y1 - y2) - y0 * (x1 - x2)) + (x1 * y2 - x2 * y1);
+        }
+        negative += (det[0] * det[1] < 0) ? 1 : 0;
+    }
+    return ok && (negative == 0 || negative == 4);
+}
+
+// the subset of hypothesis t: up to kSubsetTries draws until one passes (OpenCV re-draws inside getSubset)
+constexpr uint32_t kSubsetTries = 8;
+__device__ bool draw_checked(const float4 *pts, uint64_t seed, uint32_t b, uint32_t t, uint32_t N, uint32_t idx[4]) {
+    for (uint32_t s = 0; s < kSubsetTries; ++s) {
+        if (!draw_sample(seed, b, t, s, N, idx)) continue;
+        if (subset_ok(pts, idx)) return true;
+    }
+    return false;
+}
+
+// log(x) from + - * / only, bit for bit det_log() of the oracle (the iteration bound must not depend on a libm)
+__device__ double det_log(double x) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 0.0;
+    for (int k = 14; k >= 0; --k) s = s * t2 + 1.0 / (double)(2 * k + 1);
+    return 2.0 * t * s + (double)e * 0.6931471805599453;
+}
+
+// cv::RANSACUpdateNumIters(confidence, outlier ratio, modelPoints = 4, current bound)
+__device__ int ransac_update_iters(double conf, int good, int N, int niters) {
+    const double p = conf < 0 ? 0 : (conf > 1 ? 1 : conf);
+    double ep = (double)(N - good) / (double)N;
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1.0 - p;
+    if (num < 2.2250738585072014e-308) num = 2.2250738585072014e-308;
+    const double w = 1.0 - ep;
+    double denom = 1.0 - (w * w) * (w * w);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = det_log(num);
+    denom = det_log(denom);
+    if (denom >= 0 || -num >= (double)niters * (-denom)) return niters;
+    return (int)floor(num / denom + 0.5);
 }
 
 // value of `v` in lane `srclane`.  UNIFORM: srclane is wave-uniform -> two v_readlane_b32 (a few
@@ -129,15 +207,19 @@ __device__ __forceinline__ bool is_inlier(const double (&H)[9], const float4 p, 
 }
 
 // ---- kernel 1: hypotheses ---------------------------------------------------------------------
+// Hypotheses t0 .. T-1 of every pair; bound (or NULL): pair b only needs t < bound[b] (adaptive RANSAC), the rest leave at once.
 __global__ __launch_bounds__(256) void hyp_kernel(const float *__restrict__ pts, double *__restrict__ hyp, int Bt, int N,
-                                                  int T, uint64_t seed) {
+                                                  int T, int t0, const int *__restrict__ bound, uint64_t seed) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 7, base = lane & ~7;
+    const int TR = T - t0;
     const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;  // hypothesis id
-    const bool live = gid < (long)Bt * T;
-    const int b = live ? (int)(gid / T) : 0, t = live ? (int)(gid - (long)b * T) : 0;
+    const bool in_range = gid < (long)Bt * TR;
+    const int b = in_range ? (int)(gid / TR) : 0, t = in_range ? t0 + (int)(gid - (long)b * TR) : 0;
+    const bool live = in_range && (!bound || t < bound[b]);
+    if (!__any(live)) return;  // wave-uniform: the cross-lane solve below needs whole groups
     uint32_t idx[4] = {0, 0, 0, 0};
-    bool good = live && N >= 4 && draw_sample(seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx);
+    bool good = live && N >= 4 && draw_checked(reinterpret_cast<const float4 *>(pts) + (size_t)b * N, seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx);
     double M[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
     if (good) {
         const int k = row >> 1;
@@ -161,7 +243,7 @@ __global__ __launch_bounds__(256) void hyp_kernel(const float *__restrict__ pts,
     const unsigned long long allfin = __ballot(fin);
     good = good && (((allfin >> base) & 0xFFull) == 0xFFull);
     if (live) {
-        double *o = hyp + (size_t)gid * 9;
+        double *o = hyp + ((size_t)b * T + t) * 9;
         o[row] = good ? h : __builtin_nan("");
         if (row == 0) o[8] = good ? 1.0 : __builtin_nan("");
     }
@@ -173,12 +255,14 @@ __global__ __launch_bounds__(256) void hyp_kernel(const float *__restrict__ pts,
 // traffic per 32-pair batch and four conversions per test).
 constexpr int kHypPerWave = 4;  // 8 measured slower (register pressure / fewer waves)
 __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ pts, const double *__restrict__ hyp,
-                                                    int *__restrict__ counts, int Bt, int N, int T, double thr2) {
+                                                    int *__restrict__ counts, int Bt, int N, int T, int tbeg, const int *__restrict__ bound,
+                                                    double thr2) {
     const int lane = threadIdx.x & 63;
-    const int groups = (T + kHypPerWave - 1) / kHypPerWave;
+    const int groups = (T - tbeg + kHypPerWave - 1) / kHypPerWave;
     const long gid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gid >= (long)Bt * groups) return;
-    const int b = (int)(gid / groups), t0 = (int)(gid - (long)b * groups) * kHypPerWave;
+    const int b = (int)(gid / groups), t0 = tbeg + (int)(gid - (long)b * groups) * kHypPerWave;
+    if (bound && t0 >= bound[b]) return;  // adaptive RANSAC: the sequential loop never gets here
     double H[kHypPerWave][9];
     bool valid[kHypPerWave];
 #pragma unroll
@@ -207,8 +291,105 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ pt
     }
 }
 
+// ---- adaptive RANSAC: the head of the sequential loop ------------------------------------------------------------------
+// cv::RANSACPointSetRegistrator::run is sequential: whenever a hypothesis beats the best inlier count so far the iteration
+// bound shrinks to RANSACUpdateNumIters(confidence, ...) -- at the inlier ratios a matcher delivers, a dozen iterations
+// instead of 2000 (estimation.py:66-72 passes confidence = 0.99999).  The device keeps that outcome exactly and stays
+// parallel: (1) this kernel, one workgroup per pair, evaluates the first kHeadHyp hypotheses and applies the rule to them,
+// which gives an upper bound on where the sequential loop can stop; (2) hyp_kernel / score_kernel evaluate hypotheses
+// kHeadHyp .. bound - 1 over the whole chip (nothing at all when the bound is below kHeadHyp: the usual case);
+// (3) finish_kernel replays the rule over the counts in hypothesis order.
+// Here a thread solves its 4-point system on its own (solve_aug() of the oracle, operation for operation, matrix in LDS):
+// the 8-lanes-per-system elimination of hyp_kernel is a 20-40 us chain of cross-lane moves that only pays when thousands of
+// systems hide each other's latency.
+constexpr int kHeadHyp = 16;
+constexpr int kHeadThreads = kHeadHyp * 64;
+__global__ __launch_bounds__(kHeadThreads) void ransac_head_kernel(const float *__restrict__ pts, double *__restrict__ hyp,
+                                                                   int *__restrict__ counts, int *__restrict__ bound, int N, int T,
+                                                                   uint64_t seed, double thr2, double confidence) {
+    __shared__ double sM[72][kHeadHyp];  // augmented 8 x 9 systems, element-major: thread h owns column h
+    __shared__ double sH[kHeadHyp][9];
+    __shared__ int sCnt[kHeadHyp];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 *p = reinterpret_cast<const float4 *>(pts) + (size_t)b * N;
+    if (tid < kHeadHyp) {
+        const int h = tid, t = h;
+        uint32_t idx[4] = {0, 0, 0, 0};
+        bool good = t < T && N >= 4 && draw_checked(p, seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx);
+        if (good) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 q = p[idx[k]];
+                const double x = q.x, y = q.y, u = q.z, v = q.w;
+                const int r0 = (2 * k) * 9, r1 = (2 * k + 1) * 9;
+                sM[r0 + 0][h] = x; sM[r0 + 1][h] = y; sM[r0 + 2][h] = 1; sM[r0 + 3][h] = 0; sM[r0 + 4][h] = 0; sM[r0 + 5][h] = 0;
+                sM[r0 + 6][h] = -u * x; sM[r0 + 7][h] = -u * y; sM[r0 + 8][h] = u;
+                sM[r1 + 0][h] = 0; sM[r1 + 1][h] = 0; sM[r1 + 2][h] = 0; sM[r1 + 3][h] = x; sM[r1 + 4][h] = y; sM[r1 + 5][h] = 1;
+                sM[r1 + 6][h] = -v * x; sM[r1 + 7][h] = -v * y; sM[r1 + 8][h] = v;
+            }
+            // solve_aug(M, 8) of the oracle
+            for (int c = 0; c < 8 && good; ++c) {
+                int piv = c;
+                double best = fabs(sM[c * 9 + c][h]);
+                for (int r = c + 1; r < 8; ++r) {
+                    const double v = fabs(sM[r * 9 + c][h]);
+                    if (v > best) { best = v; piv = r; }
+                }
+                if (!(best > 1e-300)) { good = false; break; }
+                if (piv != c)
+                    for (int k = 0; k < 9; ++k) { const double tmp = sM[c * 9 + k][h]; sM[c * 9 + k][h] = sM[piv * 9 + k][h]; sM[piv * 9 + k][h] = tmp; }
+                const double inv = 1.0 / sM[c * 9 + c][h];
+                for (int r = c + 1; r < 8; ++r) {
+                    const double f = sM[r * 9 + c][h] * inv;
+                    for (int k = c; k < 9; ++k) sM[r * 9 + k][h] = sM[r * 9 + k][h] - f * sM[c * 9 + k][h];
+                }
+            }
+            if (good) {
+                for (int r = 7; r >= 0; --r) {
+                    double sacc = sM[r * 9 + 8][h];
+                    for (int k = 7; k > r; --k) sacc = sacc - sM[r * 9 + k][h] * sM[k * 9 + 8][h];
+                    sM[r * 9 + 8][h] = sacc / sM[r * 9 + r][h];
+                }
+                for (int k = 0; k < 8; ++k) good = good && isfinite(sM[k * 9 + 8][h]);
+            }
+        }
+        for (int k = 0; k < 8; ++k) sH[h][k] = good ? sM[k * 9 + 8][h] : __builtin_nan("");
+        sH[h][8] = good ? 1.0 : __builtin_nan("");
+        if (t < T) {
+            double *o = hyp + ((size_t)b * T + t) * 9;
+            for (int k = 0; k < 9; ++k) o[k] = sH[h][k];
+        }
+    }
+    __syncthreads();
+    {   // inlier counts: one wave per hypothesis
+        double H[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] = sH[wave][k];
+        const bool valid = H[8] == 1.0;  // NaN marks an invalid hypothesis
+        int c = 0;
+        for (int n = lane; n < N; n += 64) c += is_inlier(H, p[n], thr2) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) sCnt[wave] = valid ? c : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int niters = N >= 4 ? T : 0, bestc = 0;
+        for (int t = 0; t < kHeadHyp && t < T; ++t) {
+            const int c = sCnt[t];
+            counts[(size_t)b * T + t] = c;
+            if (t < niters && c > (bestc > 3 ? bestc : 3)) {  // goodCount > max(maxGoodCount, modelPoints - 1)
+                bestc = c;
+                niters = ransac_update_iters(confidence, c, N, niters);
+            }
+        }
+        bound[b] = niters;  // the sequential loop stops at or before this hypothesis
+    }
+}
+
 // ---- kernel 3: per-pair finish ------------------------------------------------------------------
 constexpr int kFinThreads = 512;
+constexpr int kFinScan = 2048;
 constexpr int kFinWaves = kFinThreads / 64;
 
 struct FinShared {
@@ -224,6 +405,7 @@ struct FinShared {
     int flag;
     int best;
     int total;
+    int scan[kFinScan];  // adaptive RANSAC: a stretch of inlier counts for the sequential replay
 };
 
 // Sum over the 64 lanes of a wave (returned to every lane, fixed order).  DPP moves on the VALU instead of the ds_bpermute
@@ -405,6 +587,9 @@ struct FinParams {
     int lm_iters;
     int stage;              // 0 full, 1 stop after RANSAC, 2 stop after DLT
     int mode;               // 0 = ransac pipeline, 1 = one-shot weighted DLT
+    const int *bound;       // adaptive RANSAC: (Bt) upper bounds from the head kernel, or null (all T hypotheses were scored)
+    double confidence;
+    int *iters_used;        // (Bt) or null
 };
 
 __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
@@ -417,27 +602,60 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
 
     int cnt = 0;
     if (P.mode == 0) {
-        // ---- arg-max over hypotheses: key = (count << 32) | ~t  -> max count, lowest t ----------
-        unsigned long long key = 0;
-        for (int t = tid; t < P.T; t += kFinThreads) {
-            const unsigned long long k = ((unsigned long long)(unsigned)P.counts[(size_t)b * P.T + t] << 32) |
-                                         (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
-            key = k > key ? k : key;
-        }
+        if (!P.bound) {
+            // ---- all hypotheses scored: arg-max, key = (count << 32) | ~t  -> max count, lowest t (what the sequential loop
+            // keeps: a later hypothesis must beat the best strictly) ----------
+            unsigned long long key = 0;
+            for (int t = tid; t < P.T; t += kFinThreads) {
+                const unsigned long long k = ((unsigned long long)(unsigned)P.counts[(size_t)b * P.T + t] << 32) |
+                                             (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
+                key = k > key ? k : key;
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o);
-            key = other > key ? other : key;
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(key, o);
+                key = other > key ? other : key;
+            }
+            if (lane == 0) sh.key[wave] = key;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long k = 0;
+                for (int w = 0; w < kFinWaves; ++w) k = sh.key[w] > k ? sh.key[w] : k;
+                const int c = (int)(k >> 32);
+                sh.best = c > 3 ? (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu)) : -1;  // goodCount > modelPoints - 1
+                if (P.iters_used) P.iters_used[b] = N >= 4 ? P.T : 0;
+            }
+            __syncthreads();
+        } else {
+            // ---- adaptive RANSAC: replay cv::RANSACPointSetRegistrator::run over the counts in hypothesis order.  Counts
+            // exist for t < max(kHeadHyp, bound[b]) (head kernel + gated hyp / score launches); the bound only ever shrinks, so
+            // the loop stops inside that range (possibly inside the head, whose last update may even leave the bound below the
+            // number of hypotheses already looked at).
+            const int L = min(max(P.bound[b], kHeadHyp), P.T);
+            int niters = N >= 4 ? P.T : 0, bestc = 0, best = -1;
+            for (int c0 = 0; c0 < L; c0 += kFinScan) {  // block-uniform trip count
+                for (int t = tid; t < kFinScan && c0 + t < L; t += kFinThreads) sh.scan[t] = P.counts[(size_t)b * P.T + c0 + t];
+                __syncthreads();
+                if (tid == 0) {
+                    const int n = min(kFinScan, L - c0);
+                    for (int k = 0; k < n; ++k) {
+                        const int t = c0 + k;
+                        if (t >= niters) break;
+                        const int c = sh.scan[k];
+                        if (c > (bestc > 3 ? bestc : 3)) {  // goodCount > max(maxGoodCount, modelPoints - 1)
+                            bestc = c; best = t;
+                            niters = ransac_update_iters(P.confidence, c, N, niters);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                sh.best = best;
+                if (P.iters_used) P.iters_used[b] = niters;
+            }
+            __syncthreads();
         }
-        if (lane == 0) sh.key[wave] = key;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long k = 0;
-            for (int w = 0; w < kFinWaves; ++w) k = sh.key[w] > k ? sh.key[w] : k;
-            const int c = (int)(k >> 32);
-            sh.best = c > 0 ? (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu)) : -1;
-        }
-        __syncthreads();
         const int best = sh.best;
         if (tid < 9) sh.H[tid] = best >= 0 ? P.hyp[((size_t)b * P.T + best) * 9 + tid] : (tid == 8 ? 1.0 : 0.0);
         __syncthreads();
@@ -642,15 +860,22 @@ GFN_EXPORT int gfn_convert_matches(const float *matches, float *pts, int64_t n, 
 }
 
 GFN_EXPORT int64_t gfn_homography_scratch_bytes(int Bt, int iters) {
-    // hypotheses (9 doubles) + counts (int), rounded up
-    return (int64_t)Bt * iters * (9 * 8 + 4) + 256;
+    // hypotheses (9 doubles) + counts (int) + the per-pair iteration bounds of the adaptive rule, rounded up
+    return (int64_t)Bt * iters * (9 * 8 + 4) + (int64_t)Bt * 4 + 256;
 }
 
 GFN_EXPORT int gfn_homography_ransac(const float *pts, int Bt, int N, double thresh, int iters, uint64_t seed, int lm_iters,
                                      int stage, double *H, int *ninl, int *best_t, unsigned char *mask, void *scratch,
                                      int64_t scratch_bytes, gfn_stream_t stream) {
+    return gfn_homography_ransac_ex(pts, Bt, N, thresh, iters, 0.0, seed, lm_iters, stage, H, ninl, best_t, mask, nullptr, scratch, scratch_bytes,
+                                    stream);
+}
+
+GFN_EXPORT int gfn_homography_ransac_ex(const float *pts, int Bt, int N, double thresh, int iters, double confidence, uint64_t seed,
+                                        int lm_iters, int stage, double *H, int *ninl, int *best_t, unsigned char *mask, int *iters_used,
+                                        void *scratch, int64_t scratch_bytes, gfn_stream_t stream) {
     if (!pts || !H || !ninl || !best_t) return gfn::fail(GFN_ERR_INVALID_ARG, "homography_ransac: null pointer");
-    if (Bt < 0 || N < 0 || iters <= 0 || !(thresh > 0) || lm_iters < 0 || stage < 0 || stage > 2)
+    if (Bt < 0 || N < 0 || iters <= 0 || !(thresh > 0) || lm_iters < 0 || stage < 0 || stage > 2 || !(confidence < 1.0))
         return gfn::fail(GFN_ERR_INVALID_ARG, "homography_ransac: bad argument");
     if ((uintptr_t)pts & 15) return gfn::fail(GFN_ERR_INVALID_ARG, "homography_ransac: pts must be 16-byte aligned");
     if (!scratch || scratch_bytes < gfn_homography_scratch_bytes(Bt, iters))
@@ -660,16 +885,30 @@ GFN_EXPORT int gfn_homography_ransac(const float *pts, int Bt, int N, double thr
     hipStream_t s = (hipStream_t)stream;
     double *hyp = reinterpret_cast<double *>(scratch);
     int *counts = reinterpret_cast<int *>(hyp + (size_t)Bt * iters * 9);
-    const long nh = (long)Bt * iters;
-    hipLaunchKernelGGL(hyp_kernel, dim3((unsigned)((nh * 8 + 255) / 256)), dim3(256), 0, s, pts, hyp, Bt, N, iters, seed);
-    if (int e = gfn::check_launch("hyp_kernel")) return e;
-    const long ngroups = (long)Bt * ((iters + kHypPerWave - 1) / kHypPerWave);
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pts, hyp, counts, Bt, N, iters,
-                       thresh * thresh);
-    if (int e = gfn::check_launch("score_kernel")) return e;
+    int *bound = nullptr;
+    int tbeg = 0;
+    if (confidence > 0) {
+        // the iteration bound follows the best inlier ratio (OpenCV's control flow): the head of the loop per pair, then only
+        // the hypotheses the sequential loop can still reach
+        bound = counts + (size_t)Bt * iters;
+        hipLaunchKernelGGL(ransac_head_kernel, dim3(Bt), dim3(kHeadThreads), 0, s, pts, hyp, counts, bound, N, iters, seed, thresh * thresh,
+                           confidence);
+        if (int e = gfn::check_launch("ransac_head_kernel")) return e;
+        tbeg = kHeadHyp;
+    }
+    if (iters > tbeg) {
+        const long nh = (long)Bt * (iters - tbeg);
+        hipLaunchKernelGGL(hyp_kernel, dim3((unsigned)((nh * 8 + 255) / 256)), dim3(256), 0, s, pts, hyp, Bt, N, iters, tbeg, bound, seed);
+        if (int e = gfn::check_launch("hyp_kernel")) return e;
+        const long ngroups = (long)Bt * ((iters - tbeg + kHypPerWave - 1) / kHypPerWave);
+        hipLaunchKernelGGL(score_kernel, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pts, hyp, counts, Bt, N, iters, tbeg, bound,
+                           thresh * thresh);
+        if (int e = gfn::check_launch("score_kernel")) return e;
+    }
     FinParams P;
     P.pts = pts; P.weight = nullptr; P.hyp = hyp; P.counts = counts; P.H = H; P.ninl = ninl; P.best_t = best_t; P.mask = mask;
     P.N = N; P.T = iters; P.thr2 = thresh * thresh; P.lm_iters = lm_iters; P.stage = stage; P.mode = 0;
+    P.bound = bound; P.confidence = confidence; P.iters_used = iters_used;
     hipLaunchKernelGGL(finish_kernel, dim3(Bt), dim3(kFinThreads), 0, s, P);
     return gfn::check_launch("finish_kernel");
 }
@@ -682,6 +921,7 @@ GFN_EXPORT int gfn_homography_dlt(const float *pts, const float *weight, int Bt,
     FinParams P;
     P.pts = pts; P.weight = weight; P.hyp = nullptr; P.counts = nullptr; P.H = H; P.ninl = ok; P.best_t = nullptr; P.mask = nullptr;
     P.N = N; P.T = 0; P.thr2 = 0; P.lm_iters = 0; P.stage = 0; P.mode = 1;
+    P.bound = nullptr; P.confidence = 0; P.iters_used = nullptr;
     hipLaunchKernelGGL(finish_kernel, dim3(Bt), dim3(kFinThreads), 0, (hipStream_t)stream, P);
     return gfn::check_launch("finish_kernel(dlt)");
 }

@@ -17,6 +17,7 @@ from . import ops
 
 RANSAC_THRESHOLD = 3.0   # ransacReprojThreshold (estimation.py:71)
 RANSAC_ITERS = 2000      # OpenCV's default maxIters
+RANSAC_CONFIDENCE = 0.99999  # estimation.py:70
 CORNER_ERROR_CLAMP = 70.0
 
 
@@ -43,13 +44,13 @@ def convert_coordinates(im_A_coords, im_A_to_im_B, wq, hq, wsup, hsup):
     return a, b
 
 
-def estimate_homographies(good_matches, sizes, thresh=RANSAC_THRESHOLD, iters=RANSAC_ITERS, seed=0):
-    """Batched device-side replacement of estimation.py:61-77.
+def estimate_homographies(good_matches, sizes, thresh=RANSAC_THRESHOLD, iters=RANSAC_ITERS, seed=0, confidence=RANSAC_CONFIDENCE):
+    """Batched device-side replacement of estimation.py:61-77 (RANSAC with OpenCV's confidence-driven iteration bound).
     good_matches: (Bt,N,4) or (N,4) normalised warp rows on the GPU; sizes = (w1,h1,w2,h2).
     Returns H (Bt,3,3) float64 on the device; failures are diag(0,0,1) like the reference."""
     w1, h1, w2, h2 = sizes
     pts = ops.convert_matches(good_matches, w1, h1, w2, h2)
-    H, _, _ = ops.find_homography(pts, thresh=thresh, iters=iters, seed=seed)
+    H, _, _ = ops.find_homography(pts, thresh=thresh, iters=iters, seed=seed, confidence=confidence)
     return H
 
 

@@ -362,10 +362,13 @@ def convert_matches(matches, wA, hA, wB, hB):
     return out
 
 
-def find_homography(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False):
-    """Batched stand-in for cv2.findHomography(pos_a, pos_b, cv2.RANSAC, ransacReprojThreshold=thresh)
-    (estimation.py:66-72), on the device.  pts (Bt,N,4) or (N,4) pixel (x,y,u,v).
-    Returns H (Bt,3,3) float64, inlier counts (Bt,), chosen hypothesis index (Bt,) [, mask (Bt,N) uint8]."""
+def find_homography(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False, confidence=0.99999,
+                    return_iters=False):
+    """Batched stand-in for cv2.findHomography(pos_a, pos_b, cv2.RANSAC, confidence=0.99999, ransacReprojThreshold=thresh)
+    (estimation.py:66-72), on the device.  pts (Bt,N,4) or (N,4) pixel (x,y,u,v).  confidence: OpenCV's termination rule
+    (the iteration bound follows the best inlier ratio; `iters` = maxIters); 0 scores all `iters` hypotheses.
+    Returns H (Bt,3,3) float64, inlier counts (Bt,), chosen hypothesis index (Bt,) [, mask (Bt,N) uint8] [, iteration bound at
+    exit (Bt,)]."""
     dev = require_gpu(pts)
     p = f32c(pts)
     if p.dim() == 2:
@@ -374,13 +377,17 @@ def find_homography(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, r
     H = torch.empty((Bt, 3, 3), device=dev, dtype=torch.float64)
     ninl = torch.empty((Bt,), device=dev, dtype=torch.int32)
     best = torch.empty((Bt,), device=dev, dtype=torch.int32)
+    used = torch.empty((Bt,), device=dev, dtype=torch.int32) if return_iters else None
     mask = torch.empty((Bt, N), device=dev, dtype=torch.uint8) if return_mask else None
     nb = int(_L().gfn_homography_scratch_bytes(Bt, int(iters)))
     scratch = torch.empty((nb // 8 + 1,), device=dev, dtype=torch.float64)
-    check(_L().gfn_homography_ransac(ptr(p), Bt, N, float(thresh), int(iters), int(seed), int(lm_iters), int(stage), ptr(H),
-                                     ptr(ninl), ptr(best), ptr(mask), ptr(scratch), nb, stream_ptr(dev)),
+    check(_L().gfn_homography_ransac_ex(ptr(p), Bt, N, float(thresh), int(iters), float(confidence or 0.0), int(seed), int(lm_iters),
+                                        int(stage), ptr(H), ptr(ninl), ptr(best), ptr(mask), ptr(used), ptr(scratch), nb, stream_ptr(dev)),
           "gfn_homography_ransac")
-    return (H, ninl, best, mask) if return_mask else (H, ninl, best)
+    out = (H, ninl, best)
+    if return_mask:
+        out = out + (mask,)
+    return out + (used,) if return_iters else out
 
 
 def homography_dlt(pts, weight=None):

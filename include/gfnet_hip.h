@@ -256,6 +256,14 @@ int64_t gfn_homography_scratch_bytes(int Bt, int iters);
 int gfn_homography_ransac(const float *pts, int Bt, int N, double thresh, int iters, uint64_t seed, int lm_iters, int stage,
                           double *H, int *ninl, int *best_t, unsigned char *mask, void *scratch, int64_t scratch_bytes,
                           gfn_stream_t stream);
+/* The same with OpenCV's termination rule (cv::RANSACPointSetRegistrator::run): 0 < confidence < 1 -- whenever a hypothesis
+ * beats the best inlier count so far the iteration bound becomes log(1 - confidence) / log(1 - w^4), w = its inlier ratio
+ * (estimation.py:66-72 passes 0.99999); confidence <= 0 scores all `iters` hypotheses like gfn_homography_ransac.  In both
+ * modes a 4-point subset with collinear points or inconsistent orientation is re-drawn (checkSubset).  iters_used (Bt) or
+ * NULL: the bound each pair stopped at. */
+int gfn_homography_ransac_ex(const float *pts, int Bt, int N, double thresh, int iters, double confidence, uint64_t seed, int lm_iters,
+                             int stage, double *H, int *ninl, int *best_t, unsigned char *mask, int *iters_used, void *scratch,
+                             int64_t scratch_bytes, gfn_stream_t stream);
 int gfn_homography_dlt(const float *pts, const float *weight, int Bt, int N, double *H, int *ok, gfn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -384,20 +384,25 @@ def homography_dlt(pts, weight=None):
     return H.reshape(Bt, 3, 3), ok
 
 
-def homography_ransac(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False):
-    """RANSAC(4-pt) -> DLT on inliers -> LM (the findHomography pipeline).  pts (Bt,N,4) pixels.
-    Returns H (Bt,3,3), inlier counts (Bt,), chosen hypothesis (Bt,) [, mask (Bt,N)]."""
+def homography_ransac(pts, thresh=3.0, iters=2000, seed=0, lm_iters=10, stage=0, return_mask=False, confidence=0.99999,
+                      return_iters=False):
+    """RANSAC(4-pt) -> DLT on inliers -> LM (the findHomography pipeline, estimation.py:66-72: confidence=0.99999 shrinks
+    the iteration bound with the best inlier ratio; confidence=0 scores all `iters` hypotheses).  pts (Bt,N,4) pixels.
+    Returns H (Bt,3,3), inlier counts (Bt,), chosen hypothesis (Bt,) [, mask (Bt,N)] [, iteration bound at exit (Bt,)]."""
     pts = np.ascontiguousarray(pts, np.float32)
     Bt, N, _ = pts.shape
     H = np.empty((Bt, 9), np.float64)
     ninl = np.empty((Bt,), np.int32)
     best = np.empty((Bt,), np.int32)
+    used = np.empty((Bt,), np.int32)
     mask = np.empty((Bt, N), np.uint8) if return_mask else None
     lib("f64").oracle_homography_ransac(_p(pts), _c_int(Bt), _c_int(N), ctypes.c_double(thresh), _c_int(iters),
-                                        ctypes.c_uint64(seed), _c_int(lm_iters), _c_int(stage), _p(H), _p(ninl), _p(best),
-                                        _p(mask))
+                                        ctypes.c_double(confidence or 0.0), ctypes.c_uint64(seed), _c_int(lm_iters), _c_int(stage),
+                                        _p(H), _p(ninl), _p(best), _p(mask), _p(used))
     out = (H.reshape(Bt, 3, 3), ninl, best)
-    return out + (mask,) if return_mask else out
+    if return_mask:
+        out = out + (mask,)
+    return out + (used,) if return_iters else out
 
 
 def homography_dlt_svd(pts, weight=None):

@@ -5,7 +5,9 @@
  * confidence=0.99999, ransacReprojThreshold=3).  OpenCV is a third-party dependency that is NOT
  * part of the reference repository and is not installed here (opencv-python, version unpinned in
  * requirements.txt:2), so this file restates the *published* findHomography pipeline
- *   RANSAC over 4-point minimal sets, reprojection threshold on squared error
+ *   RANSAC over 4-point minimal sets (subsets with collinear points or inconsistent orientation are re-drawn,
+ *   HomographyEstimatorCallback::checkSubset), reprojection threshold on squared error, the iteration bound shrinking
+ *   with the best inlier ratio (RANSACUpdateNumIters: niters = log(1 - confidence) / log(1 - w^4))
  *   -> normalised DLT on the inliers (centroid / mean-absolute-deviation normalisation, 9x9
  *      L^T L, eigenvector of the smallest eigenvalue, de-normalise, H /= H[2][2])
  *   -> Levenberg-Marquardt refinement of the 8 free parameters on the inliers (<= 10 iterations)
@@ -32,19 +34,19 @@ static inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-/* index k (0..3) of hypothesis t of pair b, attempt a */
-static inline uint32_t draw_index(uint64_t seed, uint32_t b, uint32_t t, uint32_t k, uint32_t a, uint32_t N) {
+/* index k (0..3) of hypothesis t of pair b, attempt a at the slot, subset number s of the hypothesis */
+static inline uint32_t draw_index(uint64_t seed, uint32_t b, uint32_t t, uint32_t k, uint32_t a, uint32_t s, uint32_t N) {
     uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)b << 32) | t));
-    h = splitmix64(h + ((uint64_t)k << 8) + a);
+    h = splitmix64(h + ((uint64_t)s << 16) + ((uint64_t)k << 8) + a);
     return (uint32_t)(h % N);
 }
 
 /* four distinct indices; returns 0 if that failed after 16 attempts per slot */
-static int draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t N, uint32_t idx[4]) {
+static int draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t s, uint32_t N, uint32_t idx[4]) {
     for (uint32_t k = 0; k < 4; ++k) {
         uint32_t a = 0;
         for (;;) {
-            uint32_t v = draw_index(seed, b, t, k, a, N);
+            uint32_t v = draw_index(seed, b, t, k, a, s, N);
             int dup = 0;
             for (uint32_t q = 0; q < k; ++q) dup |= (idx[q] == v);
             if (!dup) { idx[k] = v; break; }
@@ -52,6 +54,82 @@ static int draw_sample(uint64_t seed, uint32_t b, uint32_t t, uint32_t N, uint32
         }
     }
     return 1;
+}
+
+/* HomographyEstimatorCallback::checkSubset for 4 correspondences: (a) haveCollinearPoints on either image -- the last point
+ * must not lie on (or within rounding of) a line through two of the first three, nor coincide with them; (b) the four
+ * triplets must keep or all flip their orientation between the images ("Speeding-up homography estimation in mobile
+ * devices").  Plain fp64 operations in a fixed order: the GPU evaluates the same sequence. */
+#define ORACLE_FLT_EPSILON 1.1920928955078125e-07
+static int subset_ok(const float *pts, const uint32_t idx[4]) {
+    double X[2][4], Y[2][4];
+    for (int k = 0; k < 4; ++k) {
+        const float *p = pts + 4 * (size_t)idx[k];
+        X[0][k] = p[0]; Y[0][k] = p[1]; X[1][k] = p[2]; Y[1][k] = p[3];
+    }
+    for (int im = 0; im < 2; ++im)
+        for (int j = 0; j < 3; ++j) {
+            const double dx1 = X[im][j] - X[im][3], dy1 = Y[im][j] - Y[im][3];
+            for (int k = 0; k < j; ++k) {
+                const double dx2 = X[im][k] - X[im][3], dy2 = Y[im][k] - Y[im][3];
+                if (fabs(dx2 * dy1 - dy2 * dx1) <= ORACLE_FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 0;
+            }
+        }
+    static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; ++i) {
+        double det[2];
+        for (int im = 0; im < 2; ++im) {
+            const double x0 = X[im][tt[i][0]], y0 = Y[im][tt[i][0]], x1 = X[im][tt[i][1]], y1 = Y[im][tt[i][1]];
+            const double x2 = X[im][tt[i][2]], y2 = Y[im][tt[i][2]];
+            det[im] = (x0 * (y1 - y2) - y0 * (x1 - x2)) + (x1 * y2 - x2 * y1);
+        }
+        negative += (det[0] * det[1] < 0);
+    }
+    return negative == 0 || negative == 4;
+}
+
+/* the subset of hypothesis t: up to ORACLE_SUBSET_TRIES draws until one passes checkSubset (OpenCV re-draws inside
+ * getSubset); subset 0 is the stream of the earlier fixed-iteration solver */
+#define ORACLE_SUBSET_TRIES 8
+static int draw_checked(const float *pts, uint64_t seed, uint32_t b, uint32_t t, uint32_t N, uint32_t idx[4]) {
+    for (uint32_t s = 0; s < ORACLE_SUBSET_TRIES; ++s) {
+        if (!draw_sample(seed, b, t, s, N, idx)) continue;
+        if (subset_ok(pts, idx)) return 1;
+    }
+    return 0;
+}
+
+/* log(x), x > 0 and normal, from + - * / only (no libm): the CPU and the GPU must agree on every bit of the iteration bound.
+ * x = m 2^e with m in [1/sqrt2, sqrt2); log m = 2 atanh((m-1)/(m+1)), 15 odd terms (|t| <= 0.172: t^31 < 1e-23). */
+static double det_log(double x) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 0.0;
+    for (int k = 14; k >= 0; --k) s = s * t2 + 1.0 / (double)(2 * k + 1);
+    return 2.0 * t * s + (double)e * 0.6931471805599453;
+}
+
+/* cv::RANSACUpdateNumIters(confidence, outlier ratio, modelPoints = 4, current bound) */
+static int ransac_update_iters(double conf, int good, int N, int niters) {
+    double p = conf < 0 ? 0 : (conf > 1 ? 1 : conf);
+    double ep = (double)(N - good) / (double)N;
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1.0 - p;
+    if (num < 2.2250738585072014e-308) num = 2.2250738585072014e-308;
+    const double w = 1.0 - ep;
+    double denom = 1.0 - (w * w) * (w * w);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = det_log(num);
+    denom = det_log(denom);
+    if (denom >= 0 || -num >= (double)niters * (-denom)) return niters;
+    return (int)floor(num / denom + 0.5);
 }
 
 /* Solve the n x n system M x = rhs in place (Gaussian elimination, partial pivoting).
@@ -286,24 +364,31 @@ EXPORT void oracle_homography_dlt(const float *pts, const double *weight, int Bt
 
 /* RANSAC -> DLT on inliers -> LM.  pts (Bt,N,4); H (Bt,9); ninl (Bt); best_t (Bt) the chosen
  * hypothesis index (or -1); mask (Bt,N) or NULL; stage: 0 = full pipeline, 1 = stop after RANSAC
- * (H = best minimal-sample hypothesis), 2 = stop after the inlier DLT. */
-EXPORT void oracle_homography_ransac(const float *pts, int Bt, int N, double thresh, int iters, uint64_t seed, int lm_iters,
-                                     int stage, double *H, int *ninl, int *best_t, unsigned char *mask) {
+ * (H = best minimal-sample hypothesis), 2 = stop after the inlier DLT.
+ * confidence in (0,1): cv::RANSACPointSetRegistrator::run -- whenever a hypothesis beats the best inlier count so far the
+ * iteration bound becomes RANSACUpdateNumIters(confidence, ...) (estimation.py:66-72 passes 0.99999); confidence <= 0: all
+ * `iters` hypotheses are scored.  iters_used (Bt) or NULL: the bound the loop stopped at. */
+EXPORT void oracle_homography_ransac(const float *pts, int Bt, int N, double thresh, int iters, double confidence, uint64_t seed,
+                                     int lm_iters, int stage, double *H, int *ninl, int *best_t, unsigned char *mask, int *iters_used) {
     const double thr2 = thresh * thresh;
 #pragma omp parallel for schedule(dynamic)
     for (int b = 0; b < Bt; ++b) {
         const float *p = pts + (size_t)b * N * 4;
-        int best = -1, bestc = 0;
+        int best = -1, bestc = 0, niters = iters;
         double Hb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
-        for (int t = 0; t < iters && N >= 4; ++t) {
+        for (int t = 0; t < niters && N >= 4; ++t) {
             uint32_t idx[4];
             double Ht[9];
-            if (!draw_sample(seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx)) continue;
+            if (!draw_checked(p, seed, (uint32_t)b, (uint32_t)t, (uint32_t)N, idx)) continue;
             if (!solve4(p, idx, Ht)) continue;
             int c = 0;
             for (int n = 0; n < N; ++n) c += is_inlier(Ht, p + 4 * n, thr2);
-            if (c > bestc) { bestc = c; best = t; memcpy(Hb, Ht, sizeof(Hb)); }
+            if (c > (bestc > 3 ? bestc : 3)) {  /* goodCount > max(maxGoodCount, modelPoints - 1) */
+                bestc = c; best = t; memcpy(Hb, Ht, sizeof(Hb));
+                if (confidence > 0) niters = ransac_update_iters(confidence, c, N, niters);
+            }
         }
+        if (iters_used) iters_used[b] = N >= 4 ? niters : 0;
         unsigned char *mk = (unsigned char *)malloc(N > 0 ? N : 1);
         int cnt = 0;
         for (int n = 0; n < N; ++n) { mk[n] = best >= 0 && is_inlier(Hb, p + 4 * n, thr2); cnt += mk[n]; }

@@ -118,3 +118,21 @@ def test_convert_matches_is_float32_numpy_formula():
     pa, pb = oracle.convert_coordinates(m[:, :2], m[:, 2:], 640, 480, 320, 200)
     np.testing.assert_array_equal(pts[:, :2], pa.astype(np.float32))
     np.testing.assert_array_equal(pts[:, 2:], pb.astype(np.float32))
+
+
+def test_iteration_bound_follows_opencv_rule():
+    """cv::RANSACUpdateNumIters(confidence = 0.99999, modelPoints = 4): the loop stops at log(1e-5) / log(1 - w^4) once a
+    hypothesis with inlier ratio w has been seen (estimation.py:66-72 passes that confidence)."""
+    rng = np.random.default_rng(3)
+    H = random_h(rng, 448)
+    for outl, expect in ((0.0, 1), (0.3, 42), (0.6, 444)):
+        pts = make_points(rng, H, 4000, noise=0.0, outliers=outl)[None]
+        _, n, b, used = oracle.homography_ransac(pts, iters=2000, seed=9, return_iters=True)
+        w = n[0] / 4000.0
+        bound = np.log(1e-5) / np.log(1 - w ** 4) if w < 1 else 0
+        assert abs(int(used[0]) - max(int(round(bound)), 0)) <= 1 or used[0] == 2000, (outl, used, bound)
+        assert abs(used[0] - expect) <= 0.35 * expect + 2, (outl, used)
+        assert 0 <= b[0] < max(used[0], 1)
+    # confidence 0: every hypothesis is scored
+    _, _, _, used = oracle.homography_ransac(pts, iters=300, seed=9, confidence=0, return_iters=True)
+    assert used[0] == 300

@@ -223,15 +223,24 @@ def test_convert_matches_bit_exact():
 
 
 @pytest.mark.parametrize("stage", [1, 2, 0])
-def test_ransac_matches_oracle_hypothesis_for_hypothesis(stage):
+@pytest.mark.parametrize("confidence", [0.0, 0.99999])
+def test_ransac_matches_oracle_hypothesis_for_hypothesis(stage, confidence):
+    """Both control flows: all hypotheses (confidence 0) and OpenCV's confidence-driven iteration bound (estimation.py:66-72),
+    which is sequential in the oracle and chunked on the device -- chosen hypothesis, inlier count, mask and the bound the
+    loop stopped at must be bit-identical."""
     from gfnet_amd import ops
 
     Hs, pts = _points(21, 4, 3000, noise=0.6, outliers=0.35)
-    H, ninl, best, mask = ops.find_homography(dev(pts), thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True)
-    Ho, no, bo, mo = oracle.homography_ransac(pts, thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True)
+    H, ninl, best, mask, used = ops.find_homography(dev(pts), thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True,
+                                                    confidence=confidence, return_iters=True)
+    Ho, no, bo, mo, uo = oracle.homography_ransac(pts, thresh=3.0, iters=512, seed=5, stage=stage, return_mask=True, confidence=confidence,
+                                                  return_iters=True)
     np.testing.assert_array_equal(host(best), bo)   # same RNG, same counts, same tie-breaking
     np.testing.assert_array_equal(host(ninl), no)
     np.testing.assert_array_equal(host(mask), mo)
+    np.testing.assert_array_equal(host(used), uo)
+    if confidence > 0:
+        assert (uo < 512).all() and (uo > 0).all(), uo  # 65 % inliers: ~60 iterations are enough for 1 - 1e-5
     Hg = host(H)
     for b in range(4):
         assert _ace(Ho[b], Hg[b]) < 1e-3, (stage, b, _ace(Ho[b], Hg[b]))  # north_star: within 1e-3 px of the reference path
@@ -240,6 +249,46 @@ def test_ransac_matches_oracle_hypothesis_for_hypothesis(stage):
             assert _ace(Ho[b], Hg[b]) < 1e-4, (b, _ace(Ho[b], Hg[b]))
         if stage == 0:
             assert _ace(Hs[b], Hg[b]) < 0.3
+
+
+@pytest.mark.parametrize("outliers,lo,hi", [(0.0, 0, 12), (0.2, 12, 40), (0.5, 100, 400), (0.8, 2000, 2000)])
+def test_ransac_early_termination_follows_the_inlier_ratio(outliers, lo, hi):
+    """niters = log(1 - 0.99999) / log(1 - w^4): 12 at w = 1, ~23 at 0.8, ~180 at 0.5, never below maxIters at 0.2; the device
+    stops where the oracle stops, over several chunks of 64 hypotheses and for ragged N."""
+    from gfnet_amd import ops
+
+    Hs, pts = _points(31, 5, 2977, noise=0.4, outliers=outliers)
+    H, ninl, best, used = ops.find_homography(dev(pts), iters=2000, seed=3, return_iters=True)
+    Ho, no, bo, uo = oracle.homography_ransac(pts, iters=2000, seed=3, return_iters=True)
+    np.testing.assert_array_equal(host(used), uo)
+    np.testing.assert_array_equal(host(best), bo)
+    np.testing.assert_array_equal(host(ninl), no)
+    assert (uo >= lo).all() and (uo <= hi).all(), uo
+    assert (bo >= 0).all()  # (the last update may leave the bound below the index of the winner: w = 1 sets it to 0)
+    if outliers <= 0.5:
+        for b in range(5):
+            assert _ace(Ho[b], host(H)[b]) < 1e-3 and _ace(Hs[b], host(H)[b]) < 0.5
+
+
+def test_ransac_rejects_degenerate_subsets():
+    """checkSubset: with most correspondences on one line a fixed sampler keeps drawing collinear minimal sets; the solver
+    re-draws them and still finds the homography carried by the off-line points."""
+    from gfnet_amd import ops
+
+    rng = np.random.default_rng(41)
+    Hs, pts = _points(41, 1, 2000, noise=0.0, outliers=0.0)
+    line = pts[0].copy()
+    n_line = 1500
+    t = rng.uniform(20, 420, n_line)
+    line[:n_line, 0], line[:n_line, 1] = t, 0.5 * t + 30.0  # collinear in image A ...
+    x = np.concatenate((line[:n_line, :2], np.ones((n_line, 1))), 1) @ Hs[0].T
+    line[:n_line, 2:] = (x[:, :2] / x[:, 2:]).astype(np.float32)  # ... and consistent under H
+    p = line[None]
+    H, ninl, best, used = ops.find_homography(dev(p), iters=2000, seed=2, return_iters=True)
+    Ho, no, bo, uo = oracle.homography_ransac(p, iters=2000, seed=2, return_iters=True)
+    np.testing.assert_array_equal(host(best), bo)
+    np.testing.assert_array_equal(host(used), uo)
+    assert host(ninl)[0] == 2000 and _ace(Hs[0], host(H)[0]) < 1e-2
 
 
 def test_ransac_noise_free_and_failure_convention():
