@@ -97,7 +97,11 @@ def exported_symbols():
 
 def check(code, what):
     if code != 0:
-        raise GfnError(f"{what} failed ({code}): {lib().gfn_last_error().decode()}")
+        msg = lib().gfn_last_error().decode()
+        # gfn_local_corr_fwd wants its scratch counters zero on entry and only a call that ran to the end leaves them so
+        # (include/gfnet_hip.h): after any failure the cached buffers are dropped, the next call gets freshly zeroed ones
+        _scratch.clear()
+        raise GfnError(f"{what} failed ({code}): {msg}")
 
 
 def ptr(t):
@@ -126,7 +130,9 @@ _scratch = {}
 
 
 def scratch(device, nbytes):
-    """A per-(device, stream), grow-only int32 scratch buffer (stream-ordered reuse: one host thread per stream)."""
+    """A per-(device, stream), grow-only int32 scratch buffer.  Reuse is stream-ordered: any number of models may share it on
+    one stream (their launches cannot overlap), work on different streams gets different buffers; one host thread per
+    stream.  Dropped as a whole after any failed call (check())."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:

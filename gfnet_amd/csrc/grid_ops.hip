@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void interp_bilinear_pair_kernel(const float *
 
 // dflow: (B, >=2, G, G) displacement increment with batch stride dflow_bs, dcert: (B, >=1, G, G) certainty increment with
 // dcert_bs (the refiner's two outputs; one (B,3,G,G) tensor or two).  flow_in/cert_in -> flow_out/cert_out (may alias).
-__global__ __launch_bounds__(256) void flow_update_kernel(const float *__restrict__ flow_in, const float *__restrict__ cert_in,
+// flow_in / cert_in may be the same buffers as flow_out / cert_out (gfn_flow_update_fwd updates in place): no __restrict__ on them
+__global__ __launch_bounds__(256) void flow_update_kernel(const float *flow_in, const float *cert_in,
                                                           float *flow_out, float *cert_out, const float *__restrict__ dflow,
                                                           long dflow_bs, const float *__restrict__ dcert, long dcert_bs,
                                                           float *__restrict__ disp_prev, int B, int G, float scale, float div_x,

@@ -15,7 +15,8 @@ code stays PyTorch-ROCm for the FPN/transformer backbone"): pass it in as `backb
 `backbone(images, upsample) -> (pyramid_A, pyramid_B)` with the dict layout of
 GFNet.extract_features (model/network.py:156-201), or feed pyramids directly to
 `forward_pyramids` / `match_pyramids`.  The refiner's depthwise/pointwise conv stack
-(model/network.py:560-563) is ordinary torch.nn (MIOpen) -- SURVEY 8(f) N1.
+(model/network.py:560-563) runs on csrc/conv_stack.hip in eval mode; training mode keeps the nn modules and
+assembles the refiner input with differentiable torch ops (the HIP assembly has no backward).
 """
 import math
 
@@ -44,6 +45,12 @@ class ConvRefiner(nn.Module):
         super().__init__()
         if sample_mode != "bilinear":
             raise ValueError("only bilinear sampling is implemented (the reference's setting)")
+        # the reference stores these flags (network.py:496-505) and GFNet never sets them; a non-default value would change
+        # what forward() computes there, so it must not be dropped silently here
+        for name, value in (("no_im_B_fm", no_im_B_fm), ("concat_logits", concat_logits), ("use_cosine_corr", use_cosine_corr),
+                            ("is_classifier", is_classifier)):
+            if value:
+                raise NotImplementedError(f"ConvRefiner({name}=True) is not used by GFNet and is not implemented in gfnet_amd")
         self.bn_momentum = bn_momentum
 
         def block(cin, cout, bias=True):
@@ -81,9 +88,39 @@ class ConvRefiner(nn.Module):
         c = x.shape[1]
         dd = self.disp_emb.weight.shape[0]
         use_corr = bool(self.corr_in_other)
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or self.disp_emb.weight.requires_grad):
+            return self._assemble_autograd(num_grid, x, y, flow, scale_factor)
         d = ops.refiner_input(num_grid, x, y, flow, self.disp_emb.weight, self.disp_emb.bias,
                               self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr)
         return d, (d[:, 2 * c + dd:] if use_corr else None)
+
+    def _assemble_autograd(self, num_grid, x, y, flow, scale_factor):
+        """The same tensor from differentiable torch ops (network.py:537-555), for training: gradients reach the backbone
+        features through both grid_samples, disp_emb's parameters, and feature0 of the local correlation (through the HIP
+        backward gfn_local_corr_bwd_f0; the reference samples feature1 under no_grad, utils/local_correlation.py:54-60).
+        Only plain (non-symmetric) batches: training concatenates the pyramids itself."""
+        import torch.nn.functional as F
+
+        from ..utils.local_correlation import local_correlation
+
+        b, c, hs, ws = x.shape
+        G = int(num_grid)
+        if flow.shape[0] != b:
+            raise NotImplementedError("training-mode refiner input needs a plain batch (flow and features of equal batch size)")
+        x, y, flow = x.float(), y.float(), flow.float()
+        x_hat = F.grid_sample(y, flow.permute(0, 2, 3, 1), align_corners=False, mode="bilinear")              # :537
+        lin = torch.linspace(-1 + 1 / G, 1 - 1 / G, G, device=x.device)
+        gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+        coords = torch.stack((gx, gy))[None].expand(b, 2, G, G)                                                 # :539-546
+        grid_feature = F.grid_sample(x, coords.permute(0, 2, 3, 1), align_corners=False, mode="bilinear")      # :547
+        emb = self.disp_emb(40 / 32 * scale_factor * (flow - coords))                                           # :548-549
+        parts = [grid_feature, x_hat, emb]
+        lc = None
+        if self.corr_in_other:
+            lc = local_correlation((b, c, hs, ws), grid_feature, y, local_radius=self.local_corr_radius, num_grid=G, flow=flow,
+                                   sample_mode=self.sample_mode)                                                 # :553-554
+            parts.append(lc)
+        return torch.cat(parts, dim=1), lc
 
     # ---- conv stack in HIP (eval mode): BatchNorm folded, fp32 (csrc/conv_stack.hip) ----------------
     def _hip_stack_supported(self):

@@ -189,3 +189,88 @@ def test_end_to_end_known_homography_through_the_whole_path(I, dtype):
     Hp = host(E.estimate_homographies(good, (I, I, I, I), iters=256))[0]
     ace = E.corner_error(H, Hp, I, I)
     assert ace < 0.05 * I / 448, ace  # exact flow: only fp32 grid/flow rounding remains
+
+
+# ---- robustness of the boundary ---------------------------------------------------------
+def test_refiner_training_mode_backpropagates_like_the_reference():
+    """ConvRefiner.forward with grad enabled: the HIP assembly has no backward, so the input is assembled with differentiable
+    ops (network.py:537-555) -- gradients must reach the backbone features (both grid_samples and feature0 of the local
+    correlation) and disp_emb, and match a plain-torch reference refiner input."""
+    import torch.nn.functional as F
+    from gfnet_amd.model.network import ConvRefiner
+
+    torch.manual_seed(0)
+    c, disp, r, G, hs = 16, 6, 2, 12, 20
+    K = (2 * r + 1) ** 2
+    dim = 2 * c + disp + K
+    ref = ConvRefiner(dim, dim, 3, kernel_size=5, dw=True, hidden_blocks=1, displacement_emb="linear", displacement_emb_dim=disp,
+                      local_corr_num=r, corr_in_other=True, amp=False).cuda().train()
+    x = torch.randn(2, c, hs, hs, device="cuda", requires_grad=True)
+    y = torch.randn(2, c, hs, hs, device="cuda", requires_grad=True)
+    flow = (torch.rand(2, 2, G, G, device="cuda") * 1.6 - 0.8)
+    d, lc = ref.assemble(G, x, y, flow, 1.25)
+    assert d.requires_grad and lc.requires_grad
+    # the same tensor from the reference's own op sequence with a per-tap local correlation in plain torch
+    x_hat = F.grid_sample(y, flow.permute(0, 2, 3, 1), align_corners=False, mode="bilinear")
+    lin = torch.linspace(-1 + 1 / G, 1 - 1 / G, G, device="cuda")
+    gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+    coords = torch.stack((gx, gy))[None].expand(2, 2, G, G)
+    gf = F.grid_sample(x, coords.permute(0, 2, 3, 1), align_corners=False, mode="bilinear")
+    emb = ref.disp_emb(40 / 32 * 1.25 * (flow - coords))
+    ly = torch.linspace(-2 * r / hs, 2 * r / hs, 2 * r + 1, device="cuda")
+    wy, wx = torch.meshgrid(ly, ly, indexing="ij")
+    win = torch.stack((wx, wy), -1).reshape(1, 1, K, 2)
+    outs = []
+    for b in range(2):
+        with torch.no_grad():
+            cc = flow[b].permute(1, 2, 0).reshape(1, G * G, 1, 2) + win
+            samp = F.grid_sample(y[b:b + 1], cc.reshape(1, G * G, K, 2), align_corners=False, mode="bilinear")[0]  # (c, G*G, K)
+        outs.append(((gf[b].reshape(c, G * G, 1) / (c ** 0.5)) * samp).sum(0).permute(1, 0).reshape(K, G, G))
+    want = torch.cat((gf, x_hat, emb, torch.stack(outs)), 1)
+    assert_close(host(d), host(want), 1e-4, "training-mode refiner input")
+    g = torch.randn_like(d)
+    gx1, gy1, gw1 = torch.autograd.grad((d * g).sum(), (x, y, ref.disp_emb.weight), retain_graph=True)
+    gx2, gy2, gw2 = torch.autograd.grad((want * g).sum(), (x, y, ref.disp_emb.weight))
+    assert_close(host(gx1), host(gx2), 1e-4, "grad x")
+    assert_close(host(gy1), host(gy2), 1e-4, "grad y")
+    assert_close(host(gw1), host(gw2), 1e-4, "grad disp_emb")
+    dflow, dcert, _ = ref(G, x, y, flow, 1.25)  # whole forward in training mode: nn modules, differentiable
+    assert dflow.requires_grad and torch.autograd.grad(dflow.sum() + dcert.sum(), x)[0].abs().sum() > 0
+
+
+def test_refiner_rejects_flags_it_does_not_implement():
+    from gfnet_amd.model.network import ConvRefiner
+
+    for flag in ("no_im_B_fm", "concat_logits", "use_cosine_corr", "is_classifier"):
+        with pytest.raises(NotImplementedError):
+            ConvRefiner(10, 10, 3, dw=True, hidden_blocks=0, displacement_emb="linear", displacement_emb_dim=2, local_corr_num=1,
+                        corr_in_other=True, **{flag: True})
+
+
+def test_scratch_is_dropped_after_a_failed_call_and_streams_do_not_share_it():
+    from gfnet_amd import _lib
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B, c, hs, G, r = 2, 16, 24, 16, 2
+    f0 = torch.from_numpy(synth.lattice_normalish((B, c, G, G), 71)).cuda()
+    f1 = torch.from_numpy(synth.lattice_normalish((B, c, hs, hs), 72)).cuda()
+    fl = torch.from_numpy(synth.homography_flow(B, G, 73)).cuda()
+    ref = local_correlation((B, c, hs, hs), f0, f1, r, G, flow=fl)
+    torch.cuda.synchronize()
+    assert len(_lib._scratch) >= 1
+    key0 = next(iter(_lib._scratch))
+    _lib._scratch[key0][:8] = 12345  # poisoned counters, as a launch that died half-way would leave them
+    with pytest.raises(_lib.GfnError):
+        _lib.check(-2, "simulated launch failure")
+    assert len(_lib._scratch) == 0  # the next call allocates freshly zeroed scratch
+    assert torch.equal(local_correlation((B, c, hs, hs), f0, f1, r, G, flow=fl), ref)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        a = local_correlation((B, c, hs, hs), f0, f1, r, G, flow=fl)
+    with torch.cuda.stream(s2):
+        b2 = local_correlation((B, c, hs, hs), f0, f1, r, G, flow=fl)
+    torch.cuda.synchronize()
+    keys = [k for k in _lib._scratch if k[2] in (s1.cuda_stream, s2.cuda_stream)]
+    assert len(keys) == 2 and _lib._scratch[keys[0]].data_ptr() != _lib._scratch[keys[1]].data_ptr()
+    assert torch.equal(a, ref) and torch.equal(b2, ref)
