@@ -596,6 +596,13 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
     __shared__ FinShared sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = P.N;
+#ifdef GFN_ABLATE
+    long long fin_t[5] = {(long long)__builtin_readcyclecounter(), 0, 0, 0, 0};
+    int fin_lm = 0;
+#define FIN_STAMP(i) fin_t[i] = (long long)__builtin_readcyclecounter()
+#else
+#define FIN_STAMP(i) do { } while (0)
+#endif
     const float4 *pts = reinterpret_cast<const float4 *>(P.pts) + (size_t)b * N;
     const float *wgt = P.weight ? P.weight + (size_t)b * N : nullptr;
     unsigned char *mask = P.mask ? P.mask + (size_t)b * N : nullptr;
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
     double Hb[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Hb[k] = (P.mode == 0) ? sh.H[k] : 0.0;
+    FIN_STAMP(1);
 
     // ---- normalised DLT: centroid and mean absolute deviation (OpenCV runKernel) -----------------
     {
@@ -793,9 +801,13 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
     };
     if (tid < 9) sh.h[tid] = sh.H[tid] / sh.H[8];
     __syncthreads();
+    FIN_STAMP(2);
     lm_gram(sh.h, sh.G);
     double S = sh.G[80], lambda = 1e-3;
     for (int it = 0; it < P.lm_iters; ++it) {
+#ifdef GFN_ABLATE
+        ++fin_lm;
+#endif
         // solve (G8 + lambda diag) delta = -g on wave 0, one row per lane
         if (wave == 0) {
             double M[9];
@@ -807,18 +819,18 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
             const double d = ge_solve8<true>(M, row, 0, ok);
             if (lane < 8) sh.hn[lane] = sh.h[lane] + d;
             if (lane == 0) sh.hn[8] = 1.0;
-            // step / parameter norms for the stopping rule
-            double dn = (lane < 8) ? d * d : 0.0, hn2 = (lane < 8) ? sh.h[lane] * sh.h[lane] : 0.0;
-            dn = wave_sum(dn);
-            hn2 = wave_sum(hn2);
-            if (lane == 0) { sh.flag = ok ? 1 : 0; sh.stats[10] = dn; sh.stats[11] = hn2; }
+            // largest step component, for cv::LMSolver's stopping rule (epsx = FLT_EPSILON)
+            double dmax = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dmax = fmax(dmax, fabs(lane_get<true>(d, k)));
+            if (lane == 0) { sh.flag = ok ? 1 : 0; sh.stats[10] = dmax; }
         }
         __syncthreads();
         if (!sh.flag) { lambda *= 10; __syncthreads(); continue; }
         lm_gram(sh.hn, sh.G2);
         const double S2 = sh.G2[80];
         const bool accept = S2 < S;
-        const bool stop = accept && sh.stats[10] <= 1e-24 * (sh.stats[11] + 1e-24);
+        const bool stop = sh.stats[10] < 1.1920928955078125e-07;  // cv::LMSolver: the step just tried (accepted or not) is below epsx
         __syncthreads();
         if (accept) {
             if (tid < 9) sh.h[tid] = sh.hn[tid];
@@ -831,6 +843,12 @@ __global__ __launch_bounds__(kFinThreads) void finish_kernel(FinParams P) {
         __syncthreads();
         if (stop) break;
     }
+    FIN_STAMP(3);
+#ifdef GFN_ABLATE
+    if (tid == 0 && b < 3)
+        printf("finish b%d: select+mask %lld | DLT %lld | LM %lld cycles, %d LM iterations, %d inliers\n", b, fin_t[1] - fin_t[0], fin_t[2] - fin_t[1],
+               fin_t[3] - fin_t[2], fin_lm, cnt);
+#endif
     if (tid < 9) P.H[(size_t)b * 9 + tid] = sh.h[tid];
 }
 

@@ -321,8 +321,8 @@ static void lm_refine(const float *pts, const unsigned char *mask, int N, double
             M[i * 9 + 8] = -G[i * 9 + 8];
         }
         if (!solve_aug(M, 8)) { lambda *= 10; continue; }
-        double hn[9], G2[81], dn = 0, hn2 = 0;
-        for (int k = 0; k < 8; ++k) { hn[k] = h[k] + M[k * 9 + 8]; dn += M[k * 9 + 8] * M[k * 9 + 8]; hn2 += h[k] * h[k]; }
+        double hn[9], G2[81], dmax = 0;
+        for (int k = 0; k < 8; ++k) { hn[k] = h[k] + M[k * 9 + 8]; if (fabs(M[k * 9 + 8]) > dmax) dmax = fabs(M[k * 9 + 8]); }
         hn[8] = 1.0;
         lm_gram(pts, mask, N, hn, G2);
         if (G2[80] < S) {
@@ -330,10 +330,12 @@ static void lm_refine(const float *pts, const unsigned char *mask, int N, double
             memcpy(G, G2, sizeof(G));
             S = G2[80];
             lambda = lambda > 1e-11 ? lambda / 10 : 1e-12;
-            if (dn <= 1e-24 * (hn2 + 1e-24)) break;
         } else {
             lambda *= 10;
         }
+        /* cv::LMSolverImpl::run (createLMSolver(cb, 10), epsx = FLT_EPSILON): proceed while the largest component of the step
+         * just tried -- accepted or not -- is at least epsx; on a matcher's inliers that is three or four iterations, not ten */
+        if (dmax < ORACLE_FLT_EPSILON) break;
     }
     memcpy(H, h, sizeof(h));
 }

@@ -12,7 +12,7 @@ from gfnet_amd import ops  # noqa: E402
 from test_homography_cpu import make_points, random_h  # noqa: E402
 
 rng = np.random.default_rng(0)
-pts = torch.from_numpy(np.stack([make_points(rng, random_h(rng), 5000, noise=0.5, outliers=0.3) for _ in range(32)])).cuda()
+pts = torch.from_numpy(np.stack([make_points(rng, random_h(rng), 5000, noise=0.25, outliers=0.02) for _ in range(32)])).cuda()
 for _ in range(2):
     ops.find_homography(pts, iters=2000)
     torch.cuda.synchronize()
