@@ -221,8 +221,11 @@ template <> struct QuadRaw<_Float16> {
         return o;
     }
 };
+#ifndef GFN_LEAN_ST_AUX
+#define GFN_LEAN_ST_AUX 2  // 2 = nt (streaming store), 0 = plain
+#endif
 __device__ __forceinline__ void buf_st_nt(rsrc_t r, unsigned voff, unsigned soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 2);  // 2 = nt (streaming store)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, GFN_LEAN_ST_AUX);
 }
 
 // ---- staging: 16-byte quads along the row --------------------------------------------------------------------------
