@@ -34,6 +34,7 @@
 // Block->tile mapping is XCD-aware (common.h): consecutive tiles of one image stay on one XCD so
 // the 3-4x halo re-reads of f1 are served by that XCD's L2, not HBM.
 #include "common.h"
+#include "refiner_input.h"
 
 namespace {
 
@@ -68,6 +69,7 @@ struct LcParams {
     float win_xstep, win_ystep;       // ... and the linspace steps (hi - lo) / (2r), fp32 division done on the host
     int *todo;                        // [kTodoHdr + B*tiles]: header (see kTodoHdr), then the ids of the tiles left to the second launch
     long todo_ints;
+    int planned;                      // lean path: the plan is already in scratch (gfn_refiner_input_plan_fwd_dt wrote it)
     int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
@@ -815,6 +817,33 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 
 #include "local_corr_lean.h"
 
+// shapes the lean tile path takes (it keeps at most 8 channels of the f0 block per wave in registers, addresses planes with
+// 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
+bool lean_shape(int C, int H, int W, int G, int r, int f16) {
+    const long K = (long)(2 * r + 1) * (2 * r + 1);
+    return r >= 1 && r <= 4 && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
+           (long)C * G * G < (1L << 30);
+}
+
+// scratch layout of the lean path: header and tile list (ints), then the plan, 32-byte aligned
+int *lean_plan_ptr(void *scratch, int B, int G) {
+    const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
+    return reinterpret_cast<int *>(((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 31) & ~(uintptr_t)31);
+}
+
+// the window parameters every tiled launch needs (what tap_general and the plan read)
+template <int R>
+void lean_window_params(LcParams &p) {
+    p.tiles_x = (p.G + kTileW - 1) / kTileW;
+    p.tiles_y = (p.G + 3) / 4;
+    p.r = R; p.win_h = p.H; p.win_w = p.W; p.grid_based = 0;
+    p.win_xhi = (float)(2.0 * R / p.W);
+    p.win_yhi = (float)(2.0 * R / p.H);
+    const volatile float xlo = -p.win_xhi, ylo = -p.win_yhi, n1 = (float)(2 * R);
+    p.win_xstep = (p.win_xhi - xlo) / n1;
+    p.win_ystep = (p.win_yhi - ylo) / n1;
+}
+
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -863,8 +892,10 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     if constexpr (ROUNDS == 2) {
         if (lean) {
             const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
-            hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
-            if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
+            if (!p.planned) {
+                hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
+                if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
+            }
             switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
                 case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
                 case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
@@ -941,13 +972,14 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
     // the tiled path needs the tile list in scratch; without it the general kernel still gives the right answer
     // variant 0: the tiled path (lean tile kernel for r <= 4); 1: general kernel; 2: the round-1 tile kernel for every radius
     // (kept as the bit-exact cross-check of the lean kernel)
-    // the lean path keeps at most 8 channels of the f0 block per wave in registers and addresses planes with 32-bit byte offsets
-    bool lean = variant == 0 && flow && (C == 16 || C == 32 || C == 64) && !(p.f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
+    const bool planned = (variant & 8) != 0;  // gfn_refiner_input_plan_fwd_dt has already written this call's plan
+    variant &= ~8;
+    bool lean = variant == 0 && flow && !grid_based && win_h == H && win_w == W && lean_shape(C, H, W, G, r, p.f16);
+    if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
+    p.planned = planned ? 1 : 0;
     if (lean && scratch) {
-        const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
-        const uintptr_t pl = ((uintptr_t)scratch + 4 * (tiles_max + kTodoHdr) + 31) & ~(uintptr_t)31;
-        p.plan = reinterpret_cast<int *>(pl);
-        p.todo_ints = tiles_max + kTodoHdr;
+        p.plan = lean_plan_ptr(scratch, B, G);
+        p.todo_ints = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B + kTodoHdr;
     }
     const bool fast_ok = (variant == 0 || variant == 2) && !grid_based && win_h == H && win_w == W && (C % kChunk) == 0 && r >= 1 && r <= 7 &&
                          scratch && scratch_bytes >= gfn_local_corr_scratch_bytes(B, G) && ((uintptr_t)scratch & 3) == 0;
@@ -989,6 +1021,55 @@ GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f
                                   gfn_stream_t stream) {
     return gfn_local_corr_fwd_ex(f0, f0_bs, f1, f1_second, flow, out, out_bs, B, C, G, H, W, r, grid_based, win_h, win_w, 0,
                                  scratch, scratch_bytes, stream);
+}
+
+// ---- refiner input + plan in one launch ----------------------------------------------------------------------------------
+GFN_EXPORT int gfn_local_corr_plans(int C, int H, int W, int G, int r, int f1_dtype) {
+    return lean_shape(C, H, W, G, r, f1_dtype == GFN_F16) ? 1 : 0;
+}
+
+namespace {
+template <int R, typename FT>
+int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s) {
+    lean_window_params<R>(p);
+    const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
+    const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
+    const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
+    hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    return gfn::check_launch("refiner_input_plan_kernel");
+}
+}  // namespace
+
+GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int dtype, const float *flow, const float *disp_w,
+                                             const float *disp_b, float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim,
+                                             float disp_scale, int symmetric, int r, void *scratch, int64_t scratch_bytes,
+                                             gfn_stream_t stream) {
+    if (dtype != GFN_F32 && dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: feature dtype must be GFN_F32 or GFN_F16");
+    if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b))) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: null pointer");
+    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G || (symmetric && (B & 1)) ||
+        (long)C * Hs * Ws >= (1L << 31) || B > 65535 || (long)G * G >= (1L << 31))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: bad size");
+    if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: the local correlation of this shape takes no plan (ask gfn_local_corr_plans first)");
+    if (!scratch || scratch_bytes < gfn_local_corr_scratch_bytes(B, G) || ((uintptr_t)scratch & 3))
+        return gfn::fail(GFN_ERR_SCRATCH, "refiner_input_plan: scratch too small");
+    if (B == 0) return GFN_OK;
+    gfn_ri::RiArgs q;
+    q.fa = f0; q.fb = f1; q.flow = flow; q.dw = disp_w; q.db = disp_b; q.d = d; q.d_bs = (long)d_bs;
+    q.B = B; q.Bh = symmetric ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
+    LcParams p{};
+    p.flow = flow; p.f16 = dtype == GFN_F16;
+    p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
+    p.todo = reinterpret_cast<int *>(scratch);
+    p.plan = lean_plan_ptr(scratch, B, G);
+    hipStream_t s = (hipStream_t)stream;
+    const bool h = dtype == GFN_F16;
+    switch (r) {
+        case 1: return h ? launch_ri_plan<1, _Float16>(q, p, s) : launch_ri_plan<1, float>(q, p, s);
+        case 2: return h ? launch_ri_plan<2, _Float16>(q, p, s) : launch_ri_plan<2, float>(q, p, s);
+        case 3: return h ? launch_ri_plan<3, _Float16>(q, p, s) : launch_ri_plan<3, float>(q, p, s);
+        default: return h ? launch_ri_plan<4, _Float16>(q, p, s) : launch_ri_plan<4, float>(q, p, s);
+    }
 }
 
 GFN_EXPORT int gfn_local_corr_bwd_f0(const float *grad_out, int64_t grad_out_bs, const float *f1, const float *f1_second,

@@ -108,13 +108,13 @@ __device__ __forceinline__ bool region_fits(RowPlan &u) {
 
 // ---- plan launch: a wave plans kPlanPerWave tiles (all their flow loads in flight together) -----------------------------
 constexpr int kPlanPerWave = 4;
+// one wave: the plans of tiles wid0 .. wid0 + kPlanPerWave - 1 (those below `total`)
 template <int R>
-__global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
+__device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, unsigned total) {
     constexpr int PW = Lean<R>::PW;
     const int lane = threadIdx.x & 63;
     const int tiles = p.tiles_x * p.tiles_y;
-    const unsigned total = (unsigned)(p.B * tiles);
-    const unsigned wid0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kPlanPerWave;
+    if (wid0 >= total) return;
     float nx[kPlanPerWave], ny[kPlanPerWave];
     bool ok[kPlanPerWave];
 #pragma unroll
@@ -184,6 +184,26 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
                                                                                             // on one word costs ~11 ns each
         }
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
+    plan_tiles<R>(p, (blockIdx.x * 4u + (threadIdx.x >> 6)) * kPlanPerWave, (unsigned)(p.B * p.tiles_x * p.tiles_y));
+}
+
+// The refiner-input kernel and the plan of the local correlation that follows it in ConvRefiner.forward (network.py:537-555) in
+// ONE launch: blockIdx.x < q_blocks are refiner-input blocks of direction blockIdx.y, the rest plan that direction's tiles
+// (16 per block).  Both only read the flow; the plan's ~8 us and a kernel boundary disappear from the local-correlation call.
+template <int R, typename FT>
+__global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs q, LcParams p, unsigned q_blocks) {
+    const int b = gfn_ri::ri_direction(q.B, q.Bh, blockIdx.y);
+    if (blockIdx.x < q_blocks) {
+        gfn_ri::refiner_input_cell<FT>(q, b, blockIdx.x * 256u + threadIdx.x);
+        return;
+    }
+    const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
+    const unsigned first = (unsigned)b * tiles + ((blockIdx.x - q_blocks) * 4u + (threadIdx.x >> 6)) * kPlanPerWave;
+    plan_tiles<R>(p, first, (unsigned)(b + 1) * tiles);
 }
 
 // ---- buffer addressing --------------------------------------------------------------------------------------------

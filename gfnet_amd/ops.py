@@ -103,15 +103,23 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     CH = 2 * C + Dd + K
     d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
     st = stream_ptr(dev)
-    check(_L().gfn_refiner_input_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
-                                        float(40 / 32 * scale_factor), 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
+    disp_scale = float(40 / 32 * scale_factor)
+    # shapes the lean local-correlation path takes are planned inside the refiner-input launch (both only read the flow)
+    plans = corr_in_other and bool(_L().gfn_local_corr_plans(C, Hs, Ws, G, r, dtx))
     if corr_in_other:
-        out = d[:, 2 * C + Dd:]
         nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
         scr = _lib.scratch(dev, nscr)
+    if plans:
+        check(_L().gfn_refiner_input_plan_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
+                                                 disp_scale, 1 if symmetric else 0, r, ptr(scr), nscr, st), "gfn_refiner_input_plan_fwd")
+    else:
+        check(_L().gfn_refiner_input_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
+                                            disp_scale, 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
+    if corr_in_other:
+        out = d[:, 2 * C + Dd:]
         name = f"local_corr_c{C}_h{Hs}_g{G}_r{r}"
         check(_timed(name, lambda: _L().gfn_local_corr_fwd_dt(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, dtx, ptr(fl),
-                                                              c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws, 0,
+                                                              c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws, 8 if plans else 0,
                                                               ptr(scr), nscr, st)), "gfn_local_corr_fwd")
         if kernel_counters is not None:
             hdr = scr[:8].cpu()  # synchronises; header layout: csrc/local_corr.hip kTodoHdr

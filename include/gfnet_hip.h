@@ -82,7 +82,8 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
 
 /* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4, the
  * round-1 tile kernel above), 1 = force the general per-tap kernel, 2 = the round-1 tile kernel for every radius (the
- * bit-exact cross-check of the lean path).  Same arguments otherwise.
+ * bit-exact cross-check of the lean path); + 8: the plan of this call is already in scratch (gfn_refiner_input_plan_fwd_dt).  Same
+ * arguments otherwise.
  * Scratch header (ints): [0] tiles left to the second launch, [1..2] its queue counters, [3] last call's [0], [4] cells redone
  * per tap, [5] last call's [4], [6] tiles staged as two halves (sampled), [7] last call's [6]; [0..2], [4], [6] are zero
  * between calls. */
@@ -148,6 +149,15 @@ int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, c
 int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtype, const float *flow, const float *disp_w, const float *disp_b,
                              float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
                              int symmetric, gfn_stream_t stream);
+/* gfn_refiner_input_fwd_dt that, in the same launch, also plans the tiles of the local correlation that follows it in
+ * ConvRefiner.forward (model/network.py:537-555; both only read the flow): call gfn_local_corr_fwd_dt next with the same B, C,
+ * G, Hs, Ws, r, flow, dtype and scratch and variant = 8 ("plan present"), which then skips its own plan launch.  Only for shapes
+ * with gfn_local_corr_plans(...) != 0 (the lean tile path: 1 <= r <= 4, C in {16, 32, 64}, ...); scratch as for
+ * gfn_local_corr_fwd (gfn_local_corr_scratch_bytes(B, G) bytes, counters zero). */
+int gfn_local_corr_plans(int C, int H, int W, int G, int r, int f1_dtype);
+int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int dtype, const float *flow, const float *disp_w, const float *disp_b,
+                                  float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
+                                  int symmetric, int r, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
 /* F.grid_sample(in, grid, mode='bilinear', padding_mode='zeros', align_corners=False):
  * in (B,C,H,W), grid (B,Ho,Wo,2) -> out (B,C,Ho,Wo) with batch stride out_bs. */
