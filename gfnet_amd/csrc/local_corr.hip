@@ -345,9 +345,11 @@ __device__ __forceinline__ void stage_rest(float4 *s4, const FT *f1c, int H, int
 //   SECOND = true : second launch -- an irregular tile is cut into 4 x 8 sub-tiles, each staged on
 //                   its own (half the footprint along the grid row, so twice the magnification
 //                   fits); a sub-tile that still does not fit falls through to the gather variant.
-template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND, typename FT>
+template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND, typename FT, int STAGE = 68 * 1024>
 __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0, int col0, int rows, unsigned wid,
                                              unsigned char *smem) {
+    constexpr int kStageBytes = STAGE;       // shadow the file-level defaults: the lean kernel runs this path inside its own,
+    constexpr int kCapSlots = STAGE / (kSlotV4 * 16) - 1;  // smaller LDS allocation
     constexpr int PW = 2 * R + 2;            // patch width: taps -R..R plus the +1 bilinear neighbour
     constexpr int P = PW * PW;               // patch positions per cell
     constexpr int NP = (P + 15) / 16;        // positions per lane
@@ -496,7 +498,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         } else {
             __syncthreads();
             if (ABL(p, 1024)) return;
-            process_tile<R, ROUNDS, false, TW, true, FT>(p, b, row0, col0, rows, wid, smem);  // gather from L2
+            process_tile<R, ROUNDS, false, TW, true, FT, STAGE>(p, b, row0, col0, rows, wid, smem);  // gather from L2
         }
         return;
     }
@@ -775,27 +777,28 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
 
 // second launch: the tiles the staged kernel left in p.todo (their number is only known on the
 // device), re-cut into sub-tiles 8 cells wide and up to 4 rows high
-template <int R, int ROUNDS, typename FT>
-__global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// worker `me` of `nworkers`: the separate second launch (round-1 path: a workgroup of its own), or the first workgroups of the
+// lean tile kernel (which finishes the plan launch's list inside its own launch, with its own -- smaller -- stage)
+template <int R, int ROUNDS, typename FT, int STAGE>
+__device__ __forceinline__ void second_launch_worker(const LcParams &p, unsigned char *smem, int me, int nworkers) {
     constexpr int TH = 2 * ROUNDS, SH = TH < 4 ? TH : 4;  // sub-tile height
     constexpr int SUBS = (TH / SH) * (kTileW / 8);
     const int n = p.todo[0] * SUBS;
     const int tiles = p.tiles_x * p.tiles_y;
     // Only as many workgroups as there are work items take part (the rest leave at once): with no tile on the list -- the
     // common case -- the launch costs one load per workgroup instead of two contended atomics (14 us for 512 workgroups).
-    const int part = n < (int)gridDim.x ? n : (int)gridDim.x;
-    if ((int)blockIdx.x >= (part > 0 ? part : 1)) return;
+    const int part = n < nworkers ? n : nworkers;
+    if (me >= (part > 0 ? part : 1)) return;
     // work items differ by 10x (a staged sub-tile vs one that gathers from L2): after its first item (its own block id) a
     // workgroup draws tickets first come, first served
     __shared__ int next_item;
-    int it = (int)blockIdx.x;
+    int it = me;
     while (it < n) {
         const unsigned wid = (unsigned)p.todo[kTodoHdr + it / SUBS];
         const int sub = it % SUBS;
         const int b = wid / tiles, tile = wid - b * tiles;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-        process_tile<R, 1, true, 8, true, FT>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
+        process_tile<R, 1, true, 8, true, FT, STAGE>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
         __syncthreads();  // LDS (and next_item) are reused by the next sub-tile
         if (threadIdx.x == 0) next_item = part + atomicAdd(p.todo + 1, 1);
         __syncthreads();
@@ -813,6 +816,12 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
         p.todo[1] = 0;
         p.todo[2] = 0;
     }
+}
+
+template <int R, int ROUNDS, typename FT>
+__global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    second_launch_worker<R, ROUNDS, FT, kStageBytes>(p, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 #include "local_corr_lean.h"
@@ -847,7 +856,7 @@ void lean_window_params(LcParams &p) {
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
 
 // compute units of the current device (queried once per device: hipGetDeviceProperties is slow)
@@ -902,6 +911,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
                 default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
             }
             if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
+            if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
         }
     }
     if (!(lean && ROUNDS == 2)) {

@@ -637,12 +637,29 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
 }
 
+// The first kLeanWorkers workgroups of the launch (the first to be dispatched) are the "second launch": they finish the
+// tiles the plan launch listed as not fitting the stage even in halves, with the round-1 sub-tile routine, while the other
+// workgroups stage their tiles -- no separate launch (5 us when its list is empty, ~14 us of serial tail when it holds a
+// handful of tiles) and no tail.
+// Only where the register budget allows it (r >= 3: 128 VGPRs per lane; the r <= 2 kernels live on 80 for three workgroups per
+// CU and keep the separate second launch).  One worker per CU: with a handful of listed tiles all but a few leave at once,
+// under wild flow (every tile listed, the tile workgroups leaving at once) they have the chip like the separate launch had.
+template <int R>
+constexpr int lean_workers() { return R >= 3 ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
+
 template <int R, int NCH, typename FT>
 __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kLeanWorkers = lean_workers<R>();
+    if constexpr (kLeanWorkers > 0) {
+        if (blockIdx.x < kLeanWorkers) {  // block-uniform
+            second_launch_worker<R, 2, FT, Lean<R>::kStage>(p, smem, (int)blockIdx.x, kLeanWorkers);
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned wid = gfn::xcd_remap(blockIdx.x - kLeanWorkers, gridDim.x - kLeanWorkers);
     // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
     // have in the vector-memory pipeline
     typedef int i32x8 __attribute__((ext_vector_type(8)));
