@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="override the workload's pairs per GPU (per size)")
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs per size for the CPU-oracle baseline leg (0 = skip; default: per workload)")
     ap.add_argument("--breakdown", action="store_true", help="print per-stage GPU times of one step to stderr")
-    ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16"), default="off",
+    ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
     args = ap.parse_args()

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "gfn_resize_normalize_fwd": [c_vp, c_i64, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp],
     "gfn_conv_block_pack": [c_vp] * 7 + [c_int] * 2 + [c_vp],
     "gfn_conv_block_fwd": [c_vp] * 4 + [c_int] * 5 + [c_vp],
+    "gfn_conv_block_half_fwd": [c_vp, c_int, c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_pointwise_conv_fwd": [c_vp] * 4 + [c_int] * 4 + [c_vp],
 }
 # entry points that return a size instead of a status

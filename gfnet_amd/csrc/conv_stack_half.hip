@@ -1,0 +1,39 @@
+// conv_stack_half.hip -- the refiners' conv blocks on fp16 maps (the reference's amp=True class).
+//
+// Reference: ConvRefiner.forward, model/network.py:560-562 -- `with torch.autocast("cuda", enabled=self.amp, dtype=self.amp_dtype)`
+// around block1 + hidden_blocks: every map between two blocks is a float16 tensor there.  Same fused kernel as
+// csrc/conv_stack.hip's fp16-operand variant (csrc/conv_block_fused.h: depthwise, BatchNorm and accumulation in fp32, 1x1
+// operands fp16) with the maps between blocks stored as fp16 in HBM, channel pairs side by side ((B, ceil(C/2), G, G) half2):
+// the blocks of the fine scales (C = 24, 73 on 128^2 .. 320^2 maps) are bound by that traffic, and it halves.
+// The first block of a stack reads the fp32 concat `d`, the last one (out_conv folded in) writes fp32.
+#include "conv_block_fused.h"
+
+namespace {
+
+template <bool HIN, bool HOUT>
+int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, hipStream_t s) {
+    const float *xf = (const float *)x;
+    float *yf = (float *)y;
+    if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
+    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
+    return launch_fused<8, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
+}
+
+}  // namespace
+
+GFN_EXPORT int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *packed, void *y, int y_dtype, int B, int C, int M,
+                                       int G, gfn_stream_t stream) {
+    if (!x || !packed || !y || B < 0 || C <= 0 || M <= 0 || G <= 0) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: bad argument");
+    if ((x_dtype != GFN_F32 && x_dtype != GFN_F16) || (y_dtype != GFN_F32 && y_dtype != GFN_F16))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: map dtypes must be GFN_F32 or GFN_F16");
+    if (x_dtype == GFN_F32 && y_dtype == GFN_F32)
+        return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: fp32 in and out is gfn_conv_block_fwd (variant 2)");
+    if (x == y) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: in-place is not supported (cells read their neighbours)");
+    if (G & 3) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: grid side must be a multiple of 4 (got %d)", G);
+    if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: C*G*G must fit 31 bits");
+    if (B == 0) return GFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == GFN_F32) return launch_half<false, true>(x, packed, y, B, C, M, G, s);
+    if (y_dtype == GFN_F32) return launch_half<true, false>(x, packed, y, B, C, M, G, s);
+    return launch_half<true, true>(x, packed, y, B, C, M, G, s);
+}

@@ -146,7 +146,7 @@ def main(argv=None):
     ap.add_argument("--backbone", required=True, help="module:function returning the backbone callable")
     ap.add_argument("--batch_size", type=int, default=32)
     ap.add_argument("--ext", default=None)
-    ap.add_argument("--conv_precision", choices=("fp32", "fp16"), default="fp32")
+    ap.add_argument("--conv_precision", choices=("fp32", "fp16", "amp"), default="fp32")
     ap.add_argument("--refiner_ckpt", default=None, help="torch checkpoint with a 'model' state_dict (conv_refiner.* entries are loaded)")
     args = ap.parse_args(argv)
     rank, world, _ = parallel.init_from_env()

@@ -165,14 +165,29 @@ class ConvRefiner(nn.Module):
         kernel per block, two ping-pong maps."""
         fold, out_conv = self.folded_stack()
         if variant is None:
-            if self.conv_precision not in ("fp32", "fp16"):
-                raise ValueError("conv_precision must be 'fp32' or 'fp16'")
-            variant = 2 if self.conv_precision == "fp16" else 0
+            if self.conv_precision not in ("fp32", "fp16", "amp"):
+                raise ValueError("conv_precision must be 'fp32', 'fp16' (1x1 operands) or 'amp' (fp16 operands and maps)")
+            if self.conv_precision == "amp" and d.shape[-1] % 4 == 0 and d.shape[-1] == d.shape[-2]:
+                return self._conv_stack_half(d, fold, out_conv)
+            variant = 2 if self.conv_precision in ("fp16", "amp") else 0
         x, bufs = d, [None, None]
         for i, (packed, M) in enumerate(fold):
             if bufs[i & 1] is None or bufs[i & 1].shape[1] != M:
                 bufs[i & 1] = torch.empty((d.shape[0], M) + tuple(d.shape[2:]), device=d.device, dtype=torch.float32)
             x = ops.conv_block(x, packed, M, out=bufs[i & 1], variant=variant)
+        return x if out_conv is None else ops.pointwise_conv(x, out_conv[0], out_conv[1])
+
+    def _conv_stack_half(self, d, fold, out_conv):
+        """The reference's amp=True class (network.py:560-562: autocast around block1 + hidden_blocks): the maps between
+        blocks are float16 in HBM (ops.conv_block_half); out_conv runs on float32 (`.float()`, :563) -- folded into the
+        last block, which then writes float32."""
+        x, C, bufs = d, d.shape[1], [None, None]
+        for i, (packed, M) in enumerate(fold):
+            last = i == len(fold) - 1
+            x = ops.conv_block_half(x, packed, C, M, out=None if last else bufs[i & 1], out_half=not last)
+            if not last:
+                bufs[i & 1] = x
+            C = M
         return x if out_conv is None else ops.pointwise_conv(x, out_conv[0], out_conv[1])
 
     def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None):

@@ -474,6 +474,40 @@ def conv_block(x, packed, M, out=None, variant=0, t_scratch=None):
     return out
 
 
+def conv_block_half(x, packed, C, M, out=None, out_half=True):
+    """conv_block on fp16 maps (the reference's amp=True class, model/network.py:560-562): x is (B,C,G,G) float32 or a
+    half map (B,ceil(C/2),G,G,2) float16 (channel pairs side by side); returns a half map (B,ceil(M/2),G,G,2), or (B,M,G,G)
+    float32 with out_half=False.  Depthwise/BatchNorm/accumulation fp32, 1x1 operands fp16."""
+    dev = require_gpu(x, packed)
+    x_half = x.dtype == torch.float16
+    if x_half:
+        if x.dim() != 5 or x.shape[1] != (C + 1) // 2 or x.shape[4] != 2 or not x.is_contiguous():
+            raise ValueError("conv_block_half: a half map is a contiguous (B, ceil(C/2), G, G, 2) float16 tensor")
+    else:
+        x = f32c(x)
+        if x.dim() != 4 or x.shape[1] != C:
+            raise ValueError("conv_block_half: x must be (B, C, G, G)")
+    B, G, G2 = x.shape[0], x.shape[2], x.shape[3]
+    if G != G2:
+        raise ValueError("conv_block_half: square grids only")
+    if packed.numel() != int(_L().gfn_conv_block_packed_floats(C, M)):
+        raise ValueError("conv_block_half: packed parameters do not match (C=%d, M=%d)" % (C, M))
+    shape = (B, (M + 1) // 2, G, G, 2) if out_half else (B, M, G, G)
+    dt = torch.float16 if out_half else torch.float32
+    if out is None or tuple(out.shape) != shape or out.dtype != dt:
+        out = torch.empty(shape, device=dev, dtype=dt)
+    check(_timed("conv_block_half_c%d_g%d" % (C, G), lambda: _L().gfn_conv_block_half_fwd(
+        ptr(x), _lib.GFN_F16 if x_half else _lib.GFN_F32, ptr(packed), ptr(out), _lib.GFN_F16 if out_half else _lib.GFN_F32, B, C, M, G,
+        stream_ptr(dev))), "gfn_conv_block_half_fwd")
+    return out
+
+
+def half_map_to_float(h, C):
+    """(B, ceil(C/2), G, G, 2) float16 half map -> (B, C, G, G) float32 (tests, debugging)."""
+    B, NP, G, G2, _ = h.shape
+    return h.permute(0, 1, 4, 2, 3).reshape(B, 2 * NP, G, G2)[:, :C].float()
+
+
 def pointwise_conv(t, w, bias, out=None):
     """Conv2d(K, M, 1)(t) for a few output channels: out_conv (model/network.py:505,563).  w (M,K)."""
     dev = require_gpu(t, w)

@@ -316,6 +316,15 @@ int gfn_conv_block_fwd(const float *x, const float *packed, float *y, float *t_s
 int gfn_pointwise_conv_fwd(const float *w, const float *bias, const float *t, float *y, int B, int M, int K, int N,
                            gfn_stream_t stream);
 
+/* gfn_conv_block_half_fwd: the same block with fp16 maps in HBM -- the reference's amp=True refiners, where every map
+ *   between two blocks is a float16 tensor (torch.autocast around block1 + hidden_blocks, model/network.py:560-562).
+ *   Arithmetic as gfn_conv_block_fwd variant 2 (depthwise, BatchNorm and accumulation fp32, 1x1 operands fp16); a map of
+ *   dtype GFN_F16 is (B, ceil(C/2), G, G) of half2: channels 2p and 2p+1 of a cell side by side, the odd channel past C zero
+ *   (the kernel writes it so).  x_dtype / y_dtype: GFN_F32 (B, C, G, G) floats or GFN_F16; at least one of them GFN_F16 (a
+ *   stack's first block reads the fp32 concat, its last one writes fp32).  G must be a multiple of 4. */
+int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *packed, void *y, int y_dtype, int B, int C, int M, int G,
+                            gfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

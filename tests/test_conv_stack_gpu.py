@@ -74,6 +74,55 @@ def test_conv_block_fp16_operands(B, C, M, G):
     assert err <= 4e-3 * max(mag, 1.0), (err, mag)
 
 
+def _to_half_map(x):
+    """(B, C, G, G) float -> the half map layout (B, ceil(C/2), G, G, 2) float16, odd channel past C zero."""
+    B, C, G, _ = x.shape
+    xp = torch.zeros(B, 2 * ((C + 1) // 2), G, G, device=x.device, dtype=torch.float16)
+    xp[:, :C] = x.half()
+    return xp.reshape(B, (C + 1) // 2, 2, G, G).permute(0, 1, 3, 4, 2).contiguous()
+
+
+HALF_CASES = [c for c in CASES if c[3] % 4 == 0]
+
+
+@pytest.mark.parametrize("B,C,M,G", HALF_CASES)
+def test_conv_block_half_maps(B, C, M, G):
+    """fp16 maps in HBM (the reference's autocast class, network.py:560-562): fp32 -> half, half -> half and half -> fp32
+    blocks are the fp16-operand block (variant 2) on the rounded input, with the output rounded to fp16 where it is a map."""
+    from gfnet_amd import ops
+
+    x, (w, cb, alpha, beta, pw, pb), _ = _block_case(B, C, M, G, bias=(C % 2 == 1))
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    xh = x.half().float()  # what a half map holds
+    ref32 = ops.conv_block(xh, packed, M, variant=2)
+    first = ops.conv_block_half(x, packed, C, M)  # fp32 in (not rounded), half out
+    assert first.shape == (B, (M + 1) // 2, G, G, 2) and first.dtype == torch.float16
+    assert torch.equal(ops.half_map_to_float(first, M), ops.conv_block(x, packed, M, variant=2).half().float())
+    hm = _to_half_map(x)
+    mid = ops.conv_block_half(hm, packed, C, M)
+    assert torch.equal(ops.half_map_to_float(mid, M), ref32.half().float())
+    if M % 2:  # the odd channel past M is written as zero: the next block reads it
+        assert float(mid.reshape(B, (M + 1) // 2, G * G, 2)[:, -1, :, 1].abs().max()) == 0.0
+    last = ops.conv_block_half(hm, packed, C, M, out_half=False)
+    assert last.dtype == torch.float32 and torch.equal(last, ref32)
+    with pytest.raises(ValueError):
+        ops.conv_block_half(hm, packed, C + 2, M)  # not the map's channel count
+
+
+def test_conv_block_half_rejects_bad_arguments():
+    from gfnet_amd import _lib, ops
+    from gfnet_amd._lib import GfnError, ptr, stream_ptr
+
+    x, (w, cb, alpha, beta, pw, pb), _ = _block_case(1, 8, 8, 10)  # G % 4 != 0
+    packed = ops.conv_block_pack(w, cb, alpha, beta, pw, pb)
+    with pytest.raises(GfnError):
+        ops.conv_block_half(x, packed, 8, 8)
+    x8 = _rand(1, 8, 8, 8)
+    out = torch.empty(1, 8, 8, 8, device="cuda")
+    rc = _lib.lib().gfn_conv_block_half_fwd(ptr(x8), _lib.GFN_F32, ptr(packed), ptr(out), _lib.GFN_F32, 1, 8, 8, 8, stream_ptr(x8.device))
+    assert rc != 0  # fp32 in and out is gfn_conv_block_fwd's job
+
+
 @pytest.mark.parametrize("variant", [0, 2])
 def test_conv_block_large_grid_two_items_per_workgroup(variant):
     """>= 16384 work items: the launcher gives every workgroup two consecutive tiles (pipelined back to back, zero
@@ -158,6 +207,15 @@ def test_conv_stack_matches_torch_modules(feat, disp, r, G, B):
     err_amp, _ = _maxerr(want16, want)
     assert err16 <= 2e-2 * max(mag, 1.0), (err16, mag)
     assert err16 <= 2.0 * err_amp + 1e-6, (err16, err_amp)
+    # amp: fp16 maps between the blocks too -- what torch's autocast does; as close to fp32 as torch's own autocast
+    with torch.no_grad():
+        ref.conv_precision = "amp"
+        got_amp = ref.conv_stack(d)
+        ref.conv_precision = "fp32"
+    err_hm, _ = _maxerr(got_amp, want)
+    assert got_amp.dtype == torch.float32 and got_amp.shape == want.shape
+    assert err_hm <= 2e-2 * max(mag, 1.0), (err_hm, mag)
+    assert err_hm <= 2.0 * err_amp + 1e-6, (err_hm, err_amp)
     # a changed running statistic invalidates the folded parameters
     with torch.no_grad():
         ref.block1[1].running_mean.add_(0.5)
