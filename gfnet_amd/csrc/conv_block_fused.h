@@ -78,8 +78,14 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     static_assert(F16 || !(HIN || HOUT), "fp16 maps go with fp16 1x1 operands");
 #ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
     const int dbg = dbg_arg;
+    // bit 64: s_memtime stamps at the phase boundaries of a few workgroups (device printf at the end)
+    const bool stamping = (dbg & 64) && (blockIdx.x % 997) == 500 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 1) == 0;
+    long long stamp[40];
+    for (int i = 0; i < 40; ++i) stamp[i] = 0;
+#define CSTAMP(i) do { if (stamping && (i) < 40) stamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
     constexpr int dbg = 0;
+#define CSTAMP(i) do { } while (0)
 #endif
     static_assert(NB == 1 || (NB == 2 && NS == 1 && MT <= 3), "256-cell tiles: one slab of at most 96 output channels");
     constexpr int NT = 256 * NS;
@@ -112,6 +118,11 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     // threads write consecutive 16-byte pieces, the matrix lanes read consecutive dwords
     __shared__ __attribute__((aligned(16))) float Bs[F16 ? kNP * BN : kKT * BN];
     __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
+    // The 1x1 bias of the item's output slabs, by item parity.  It rides the load pipeline (fetched with an item's first K tile,
+    // filed at that tile's commit): fetched in the epilogue its wait would be vmcnt(0) -- on gfx9 that also waits for the next
+    // item's prefetch and for the previous accumulator tile's stores to be acknowledged (measured: the store phase cost as
+    // much as the depthwise).
+    __shared__ __attribute__((aligned(16))) float Bias_s[2][BMS];
 
     const PackDims pd(K, M);
     const float *cp = packed + pd.cp_off();
@@ -171,10 +182,13 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     static_assert(APT <= 4, "weight tile slots");
+    static_assert(BMS <= NT, "one bias value per thread");
     float4 xr0[XPP], xr1[HIN ? 1 : XPP];
     float4 ar0, ar1, ar2, ar3;  // named, not an array: the compiler demotes a float4 array here to LDS
     float pr[PPT];
-    int r_valid = 0;  // l_valid of the item in the registers; bit 8: its first K tile (refresh the zero padding)
+    int r_valid = 0;  // l_valid of the item in the registers; bit 8: its first K tile (refresh the zero padding); bit 9: a first K
+                      // tile (file the bias), bit 10: the item's parity
+    float bias_r = 0.f;
     const float4 *wt4 = reinterpret_cast<const float4 *>(F16 ? packed + pd.wt16_off() : wt);
     auto a_load = [&](int kt, int i) {
         const int e = tid + NT * i;
@@ -207,6 +221,11 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
 #pragma unroll
         for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
         r_valid = l_valid | (l_kt == 0 && l_item != w_begin ? 256 : 0);
+        if (l_kt == 0) {
+            r_valid |= 512 | (((l_item - w_begin) & 1u) ? 1024 : 0);
+            const int m = l_m0 + tid;
+            bias_r = bias[tid < BMS && m < Mp ? m : 0];  // padded to Mp
+        }
         if (++l_kt == nk) {
             l_kt = 0;
             if (++l_item < w_end) load_stage_enter_item();
@@ -239,6 +258,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 3) a_store(buf, 3, ar3);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) Ps[tid + NT * i] = pr[i];
+        if ((r_valid & 512) && tid < BMS) Bias_s[(r_valid >> 10) & 1][tid] = bias_r;
     };
 
     f32x16 acc[NB * MT];  // [cell half g][row tile i]
@@ -265,16 +285,22 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     float *dw_dst = &Bs[(F16 ? dp : 2 * dp) * BN + dr * TW + dc];  // fp32: channel 2dp here, 2dp+1 one plane (BN) further
 
     if (total <= 0) return;
+    CSTAMP(0);
     load_stage_enter_item();
     issue();
+    CSTAMP(1);
     __syncthreads();  // Xs zeroed
+    CSTAMP(2);
     unsigned c_item = w_begin;  // the item being accumulated
     int c_kt = 0;
     for (int t = 0; t < total; ++t) {
         const int buf = t & 1;
         commit(buf);
+        CSTAMP(3 + 6 * t);
         __syncthreads();
+        CSTAMP(4 + 6 * t);
         if (t + 1 < total) issue();
+        CSTAMP(5 + 6 * t);
         if (!(dbg & 2)) {  // depthwise: RB output rows x CPT cells x one channel pair; every halo row and every tap row is read once
             f32x2 a[RB][CPT];
 #pragma unroll
@@ -330,7 +356,9 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                 }
             }
         }
+        CSTAMP(6 + 6 * t);
         __syncthreads();
+        CSTAMP(7 + 6 * t);
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
             if (dbg & 4) break;
@@ -378,10 +406,12 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                 }
             }
         }
+        CSTAMP(8 + 6 * t);
         if (++c_kt < nk) continue;
         // item finished: D[row][col], col = lane&31 -> cell (g*4+cw)*32+col of the tile, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         int b, row0, col0, m0;
         decode(c_item, b, row0, col0, m0);
+        const int bpar = (int)((c_item - w_begin) & 1u);
         c_kt = 0;
         ++c_item;
 #pragma unroll
@@ -396,7 +426,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             if (mb >= M) break;
             float4 bq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4 *>(bias + mb + 8 * q + 4 * kh);  // bias is padded to Mp
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4 *>(&Bias_s[bpar][slab * BM + i * 32 + 8 * q + 4 * kh]);
             if constexpr (HOUT) {  // channels m .. m+3 of this lane's cell = two half2 dwords, 128 bytes per 32 lanes; rows past M are 0
                 float *yt = yb + (size_t)((mb + 4 * kh) >> 1) * plane;
 #pragma unroll
@@ -434,7 +464,15 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         for (int i = 0; i < NB * MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        CSTAMP(33 + (int)(c_item - w_begin));  // item stored
     }
+#ifdef GFN_ABLATE
+    if (stamping) {
+        for (int i = 1; i < 40; ++i)
+            if (stamp[i]) printf("CS %u %d %d %lld\n", blockIdx.x, (int)(threadIdx.x >> 6), i, stamp[i] - stamp[0]);
+    }
+#endif
+#undef CSTAMP
 }
 
 // GFN_CONV_TPB (environment, experiments): work items per workgroup of the fused kernel, 0 = heuristic
@@ -466,7 +504,8 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
 template <int TW, bool F16, bool HIN = false, bool HOUT = false>
 int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     const int tiles = (M + 31) / 32;
-    if (F16 && tiles <= 3 && TW >= 16 && G % (2 * kBN / TW) == 0) {  // fp32: the larger tiles cost a resident workgroup (LDS)
+    static const bool nb1 = getenv("GFN_CONV_NB1") != nullptr;  // experiments: 128-cell tiles for the narrow blocks too
+    if (F16 && tiles <= 3 && TW >= 16 && G % (2 * kBN / TW) == 0 && !nb1) {  // fp32: the larger tiles cost a resident workgroup (LDS)
         if constexpr (F16 && TW >= 16) {
             switch (tiles) {
                 case 1: return launch_fused_mt<1, TW, 1, F16, 2, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);

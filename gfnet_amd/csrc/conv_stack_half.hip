@@ -11,12 +11,12 @@
 namespace {
 
 template <bool HIN, bool HOUT>
-int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, hipStream_t s) {
+int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, int dbg, hipStream_t s) {
     const float *xf = (const float *)x;
     float *yf = (float *)y;
-    if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
-    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
-    return launch_fused<8, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, 0, s);
+    if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
+    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
+    return launch_fused<8, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
 }
 
 }  // namespace
@@ -24,6 +24,11 @@ int launch_half(const void *x, const float *packed, void *y, int B, int C, int M
 GFN_EXPORT int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *packed, void *y, int y_dtype, int B, int C, int M,
                                        int G, gfn_stream_t stream) {
     if (!x || !packed || !y || B < 0 || C <= 0 || M <= 0 || G <= 0) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: bad argument");
+    int dbg = 0;
+#ifdef GFN_ABLATE  // timing experiments (tools/ablate_convblock.py): phase mask in the high bits of x_dtype
+    dbg = x_dtype >> 8;
+    x_dtype &= 0xff;
+#endif
     if ((x_dtype != GFN_F32 && x_dtype != GFN_F16) || (y_dtype != GFN_F32 && y_dtype != GFN_F16))
         return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: map dtypes must be GFN_F32 or GFN_F16");
     if (x_dtype == GFN_F32 && y_dtype == GFN_F32)
@@ -33,7 +38,7 @@ GFN_EXPORT int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *
     if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: C*G*G must fit 31 bits");
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == GFN_F32) return launch_half<false, true>(x, packed, y, B, C, M, G, s);
-    if (y_dtype == GFN_F32) return launch_half<true, false>(x, packed, y, B, C, M, G, s);
-    return launch_half<true, true>(x, packed, y, B, C, M, G, s);
+    if (x_dtype == GFN_F32) return launch_half<false, true>(x, packed, y, B, C, M, G, dbg, s);
+    if (y_dtype == GFN_F32) return launch_half<true, false>(x, packed, y, B, C, M, G, dbg, s);
+    return launch_half<true, true>(x, packed, y, B, C, M, G, dbg, s);
 }
