@@ -17,6 +17,7 @@ constexpr int kKT = 16;    // channels per K tile
 constexpr int kNP = 8;     // channel pairs per K tile
 constexpr int kBN = 128;   // cells per workgroup tile: 4 waves x 32
 constexpr int kCP2 = 64;   // floats per channel PAIR in the packed depthwise parameters
+constexpr int kMM2 = 96;   // dwords per channel PAIR in the matrix-core depthwise parameters (see PackDims::mm_off)
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -34,7 +35,11 @@ struct PackDims {
     __host__ __device__ size_t wt_off() const { return (size_t)(Kp / 2) * kCP2; }
     __host__ __device__ size_t bias_off() const { return wt_off() + (size_t)Kp * Mp; }
     __host__ __device__ size_t wt16_off() const { return bias_off() + Mp; }  // the same weights in fp16 (two per float slot)
-    __host__ __device__ size_t total() const { return wt16_off() + (size_t)Kp * Mp / 2; }
+    // matrix-core depthwise (fp16 maps): per channel pair kMM2 dwords -- [ch][dy][8] the taps of channel 2p+ch as fp16 in the
+    // low (ch = 0) or high (ch = 1) half of a dword, entries 5..7 zero (what a lane whose window misses the tap reads), then
+    // conv bias, alpha, beta of both channels as floats (80 .. 85)
+    __host__ __device__ size_t mm_off() const { return wt16_off() + (size_t)Kp * Mp / 2; }
+    __host__ __device__ size_t total() const { return mm_off() + (size_t)(Kp / 2) * kMM2; }
     // fp16 weights, in halfs from wt16_off: per K tile [k half kg][m][8], k = 16*kt + 8*kg + j: one 16-byte read = a lane's
     // A operand of v_mfma_f32_32x32x16_f16
     __host__ __device__ size_t wt16_index(int k, int m) const { return ((size_t)((k >> 4) * 2 + ((k >> 3) & 1)) * Mp + m) * 8 + (k & 7); }
@@ -69,13 +74,23 @@ __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2
 // Maps in HBM: fp32 (B, C, G, G), or -- HIN / HOUT, fp16 maps -- (B, ceil(C/2), G, G) of half2 = channels (2p, 2p+1) of a
 // cell side by side (the odd channel past C is zero): the order the halo is staged in and the order an accumulator lane
 // holds its four consecutive output channels in, so neither side shuffles.
-template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false>
+//
+// MM (fp16 maps only): the depthwise 5x5 runs on the matrix core too.  A row of 8 output cells x 2 channels is a 16-cell x
+// 2-channel window of the halo times a banded (Toeplitz) matrix of the pair's taps: v_mfma_f32_16x16x32_f16 with A = 16
+// independent row segments of the halo (fp16 in LDS exactly as it sits in HBM: a lane's 8 k values are one 16-byte piece),
+// B = the band of one tap row (built per pair from a 6-entry table), accumulated over the 5 tap rows.  85 % of the products
+// are zeros, and it still costs a fifth of the VALU form (25 v_pk_fma_f32 per cell pair); BatchNorm + ReLU stay fp32 on the
+// accumulator.  Taps rounded to fp16 (torch.autocast does the same to the conv weight).
+template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false>
+// (a fourth workgroup per CU for the narrowest blocks -- 128 VGPRs, 32 KB of LDS -- measured slower: 146/265 vs 143/218 us at
+// C = 24, 256^2 / 320^2 maps; the memory system, not the CU, is what these blocks wait for)
 __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(const float *__restrict__ x,
                                                                                const float *__restrict__ packed,
                                                                                float *__restrict__ y, int M, int K, int G,
                                                                                int tiles_x, int tiles_y, int ngrp, unsigned nwork,
                                                                                int tpb, int dbg_arg) {
     static_assert(F16 || !(HIN || HOUT), "fp16 maps go with fp16 1x1 operands");
+    static_assert(!MM || F16, "the matrix-core depthwise takes fp16 operands");
 #ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
     const int dbg = dbg_arg;
     // bit 64: s_memtime stamps at the phase boundaries of a few workgroups (device printf at the end)
@@ -101,7 +116,13 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     constexpr int GP = F16 ? 2 : 4;         // 16-byte operand groups per weight row and K tile
     constexpr int AV4 = GP * BMS;           // 16-byte pieces of one weight tile
     constexpr int APT = (AV4 + NT - 1) / NT;
-    constexpr int PPT = kNP * kCP2 / NT;    // parameter floats per thread and K tile
+    constexpr int PW = MM ? kMM2 : kCP2;    // parameter dwords per channel pair
+    constexpr int PPT = (kNP * PW + NT - 1) / NT;  // parameter dwords per thread and K tile
+    // MM: the halo in LDS is fp16, one dword = the two channels of a cell; PH dwords per halo row -- the pitch that puts the 16
+    // lanes of a ds_read_b128 group (row segment r = m % RS, chunk c = m / RS, piece kg) on distinct banks
+    constexpr int PH = TW == 8 ? 24 : 48;
+    constexpr int CHK = TW / 8, RS = 16 / CHK;  // 8-cell chunks per tile row, rows per 16-segment sub-tile
+    static_assert(!MM || TH == RS * NB, "sub-tiles of 16 row segments");
     constexpr int CPT = 4 / NS;             // depthwise: cells per thread and row
     constexpr int RB = NB;                  //            rows per thread
     constexpr int TPP = kBN / CPT;          //            threads per channel pair
@@ -111,13 +132,13 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     // ds_read_b128 group back on all 32 banks (measured: 69% of LDS cycles were bank conflicts without it).
     constexpr bool SWZ = NB == 2;
 
-    __shared__ __attribute__((aligned(16))) float Xs[kNP * PP];
+    __shared__ __attribute__((aligned(16))) float Xs[MM ? kNP * HR * PH : kNP * PP];
     // fp32: [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3;  fp16: [buf][kg*BMS + m] = 8 halfs k = 8kg ..
     __shared__ float4 As4[2][GP * BMS];
     // B operand tile: fp32 [channel k][cell]; fp16 [pair][cell] of half2 (channels 2p, 2p+1) -- consecutive depthwise
     // threads write consecutive 16-byte pieces, the matrix lanes read consecutive dwords
     __shared__ __attribute__((aligned(16))) float Bs[F16 ? kNP * BN : kKT * BN];
-    __shared__ __attribute__((aligned(16))) float Ps[kNP * kCP2];
+    __shared__ __attribute__((aligned(16))) float Ps[kNP * PW];
     // The 1x1 bias of the item's output slabs, by item parity.  It rides the load pipeline (fetched with an item's first K tile,
     // filed at that tile's commit): fetched in the epilogue its wait would be vmcnt(0) -- on gfx9 that also waits for the next
     // item's prefetch and for the previous accumulator tile's stores to be acknowledged (measured: the store phase cost as
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     __shared__ __attribute__((aligned(16))) float Bias_s[2][BMS];
 
     const PackDims pd(K, M);
-    const float *cp = packed + pd.cp_off();
+    const float *cp = packed + (MM ? pd.mm_off() : pd.cp_off());
     const float *wt = packed + pd.wt_off();
     const float *bias = packed + pd.bias_off();
     const int Mp = pd.Mp, Kp = pd.Kp;
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         const int p = e / (HR * RV4), rem = e - p * (HR * RV4);
         const int hr = rem / RV4, q = rem - hr * RV4;
         xp2[i] = 2 * p;
-        xl[i] = p * PP + hr * RPP + 8 * q + (SWZ && ((hr >> 1) & 1) ? 4 : 0);
+        xl[i] = MM ? p * (HR * PH) + hr * PH + 4 * q : p * PP + hr * RPP + 8 * q + (SWZ && ((hr >> 1) & 1) ? 4 : 0);
     }
     unsigned l_item = w_begin;  // load stage: the (item, K tile) the next issue() fetches
     int l_kt = 0, l_m0 = 0, l_valid = 0;  // l_valid bit i: slot i lies inside the map (else zero padding)
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         }
     };
     if (!(dbg & 32))
-        for (int e = tid; e < kNP * PP / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < (MM ? kNP * HR * PH : kNP * PP) / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     static_assert(APT <= 4, "weight tile slots");
     static_assert(BMS <= NT, "one bias value per thread");
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 2) ar2 = a_load(l_kt, 2);
         if constexpr (APT > 3) ar3 = a_load(l_kt, 3);
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * kCP2 + tid + NT * i];
+        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * PW + min(tid + NT * i, kNP * PW - 1)];
         r_valid = l_valid | (l_kt == 0 && l_item != w_begin ? 256 : 0);
         if (l_kt == 0) {
             r_valid |= 512 | (((l_item - w_begin) & 1u) ? 1024 : 0);
@@ -235,6 +256,22 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if (dbg & 16) return;
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
+            if constexpr (MM) {
+                if (r_valid & (1 << i)) {
+                    f32x4 v;
+                    if constexpr (HIN) {
+                        v = f32x4{xr0[i].x, xr0[i].y, xr0[i].z, xr0[i].w};
+                    } else {  // the fp32 concat: round to fp16 here (what autocast does to the first conv's input)
+                        const f16x8 h = {(_Float16)xr0[i].x, (_Float16)xr1[i].x, (_Float16)xr0[i].y, (_Float16)xr1[i].y,
+                                         (_Float16)xr0[i].z, (_Float16)xr1[i].z, (_Float16)xr0[i].w, (_Float16)xr1[i].w};
+                        v = __builtin_bit_cast(f32x4, h);
+                    }
+                    *reinterpret_cast<f32x4 *>(&Xs[xl[i]]) = v;
+                } else if ((r_valid & 256) && tid + NT * i < PS) {
+                    *reinterpret_cast<float4 *>(&Xs[xl[i]]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                continue;
+            }
             if (r_valid & (1 << i)) {
                 f32x4 lo, hi;
                 if constexpr (HIN) {
@@ -257,7 +294,8 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 2) a_store(buf, 2, ar2);
         if constexpr (APT > 3) a_store(buf, 3, ar3);
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) Ps[tid + NT * i] = pr[i];
+        for (int i = 0; i < PPT; ++i)
+            if (PPT * NT == kNP * PW || tid + NT * i < kNP * PW) Ps[tid + NT * i] = pr[i];
         if ((r_valid & 512) && tid < BMS) Bias_s[(r_valid >> 10) & 1][tid] = bias_r;
     };
 
@@ -301,6 +339,49 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         CSTAMP(4 + 6 * t);
         if (t + 1 < total) issue();
         CSTAMP(5 + 6 * t);
+        if constexpr (MM) {
+            if (!(dbg & 2)) {
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const int n = lane & 15, xo = n >> 1, ch = n & 1, kg = lane >> 4, mrow = lane & 15;
+                const int ar = mrow % RS, ac = mrow / RS;  // A operand: this lane's row segment
+                const float *xbase = &Xs[ar * PH + 8 * ac + 4 * kg];
+                _Float16 *bs16 = reinterpret_cast<_Float16 *>(Bs);
+                int tix[4];  // table entry of this lane's k pair i (cell 4kg + i of the window) for its output cell xo; 5 = zero
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int dx = 4 * kg + i - xo - 2;
+                    tix[i] = ch * 40 + ((unsigned)dx <= 4u ? dx : 5);
+                }
+#pragma unroll
+                for (int pi = 0; pi < kNP / (4 * NS); ++pi) {
+                    const int pr_ = wave + 4 * NS * pi;  // channel pair of the K tile
+                    const float *tw = &Ps[pr_ * kMM2];
+                    f16x8 T[5];
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy) {
+                        const f32x4v t = {tw[tix[0] + 8 * dy], tw[tix[1] + 8 * dy], tw[tix[2] + 8 * dy], tw[tix[3] + 8 * dy]};
+                        T[dy] = __builtin_bit_cast(f16x8, t);
+                    }
+                    const float cb = tw[80 + ch], al = tw[82 + ch], be = tw[84 + ch];
+#pragma unroll
+                    for (int sub = 0; sub < NB; ++sub) {
+                        f32x4v d = {0.f, 0.f, 0.f, 0.f};
+                        const float *xs = xbase + pr_ * (HR * PH) + sub * RS * PH;
+#pragma unroll
+                        for (int dy = 0; dy < 5; ++dy) {
+                            const f16x8 a = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4v *>(xs + dy * PH));
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, T[dy], d, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {  // D row 4kg + j = row segment (r, c); column n = (cell xo, channel ch)
+                            const int m = 4 * kg + j, r = m % RS, c = m / RS;
+                            const int cell = (sub * RS + r) * TW + 8 * c + xo;
+                            bs16[(pr_ * BN + cell) * 2 + ch] = (_Float16)dw_finish(d[j], cb, al, be);
+                        }
+                    }
+                }
+            }
+        } else
         if (!(dbg & 2)) {  // depthwise: RB output rows x CPT cells x one channel pair; every halo row and every tap row is read once
             f32x2 a[RB][CPT];
 #pragma unroll
@@ -434,8 +515,15 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                     const int m = mb + 8 * q + 4 * kh;
                     const f16x2 h0 = {(_Float16)(acc[g * MT + i][4 * q] + bq[q].x), (_Float16)(acc[g * MT + i][4 * q + 1] + bq[q].y)};
                     const f16x2 h1 = {(_Float16)(acc[g * MT + i][4 * q + 2] + bq[q].z), (_Float16)(acc[g * MT + i][4 * q + 3] + bq[q].w)};
-                    if (m < M) yt[(size_t)(4 * q) * plane] = __builtin_bit_cast(float, h0);
-                    if (m + 2 < M) yt[(size_t)(4 * q + 1) * plane] = __builtin_bit_cast(float, h1);
+                    // streaming stores where a wave's 32 lanes cover whole 64/128-byte lines: measured 5-12 % at C = 73 .. 417, a
+                    // loss on the 8-cell-wide tiles (32-byte row segments) and at C = 24 (one slab: 149/246 vs 143/218 us)
+                    if constexpr (TW >= 16 && MT >= 2) {
+                        if (m < M) __builtin_nontemporal_store(__builtin_bit_cast(float, h0), &yt[(size_t)(4 * q) * plane]);
+                        if (m + 2 < M) __builtin_nontemporal_store(__builtin_bit_cast(float, h1), &yt[(size_t)(4 * q + 1) * plane]);
+                    } else {
+                        if (m < M) yt[(size_t)(4 * q) * plane] = __builtin_bit_cast(float, h0);
+                        if (m + 2 < M) yt[(size_t)(4 * q + 1) * plane] = __builtin_bit_cast(float, h1);
+                    }
                 }
                 continue;
             }
@@ -481,7 +569,7 @@ static int g_conv_tpb = [] {
     return e ? atoi(e) : 0;
 }();
 
-template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false>
+template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false>
 int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     constexpr int TH = kBN * NB / TW;
     const int tiles_x = (G + TW - 1) / TW, tiles_y = (G + TH - 1) / TH;
@@ -492,7 +580,7 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
     int tpb = nwork >= 16384 ? 2 : 1;  // measured: pays only on the largest grids
     if (g_conv_tpb > 0) tpb = g_conv_tpb;
     const unsigned grid = (unsigned)((nwork + tpb - 1) / tpb);
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB, HIN, HOUT>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB, HIN, HOUT, MM>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
                        tiles_y, ngrp, (unsigned)nwork, tpb, dbg);
     return gfn::check_launch("dwpw_fused_kernel");
 }
@@ -501,37 +589,37 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
 // (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once.  Narrow blocks
 // (M <= 96: the fine scales, bound by LDS and HBM traffic rather than the matrix core) take 256-cell
 // tiles with two output rows per depthwise thread when the map divides into them.
-template <int TW, bool F16, bool HIN = false, bool HOUT = false>
+template <int TW, bool F16, bool HIN = false, bool HOUT = false, bool MM = false>
 int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     const int tiles = (M + 31) / 32;
     static const bool nb1 = getenv("GFN_CONV_NB1") != nullptr;  // experiments: 128-cell tiles for the narrow blocks too
     if (F16 && tiles <= 3 && TW >= 16 && G % (2 * kBN / TW) == 0 && !nb1) {  // fp32: the larger tiles cost a resident workgroup (LDS)
         if constexpr (F16 && TW >= 16) {
             switch (tiles) {
-                case 1: return launch_fused_mt<1, TW, 1, F16, 2, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-                case 2: return launch_fused_mt<2, TW, 1, F16, 2, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-                default: return launch_fused_mt<3, TW, 1, F16, 2, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
+                case 1: return launch_fused_mt<1, TW, 1, F16, 2, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+                case 2: return launch_fused_mt<2, TW, 1, F16, 2, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+                default: return launch_fused_mt<3, TW, 1, F16, 2, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
             }
         }
     }
     if (tiles <= 7) {
         switch (tiles) {
-            case 1: return launch_fused_mt<1, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            case 2: return launch_fused_mt<2, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            case 3: return launch_fused_mt<3, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            case 4: return launch_fused_mt<4, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            case 5: return launch_fused_mt<5, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            case 6: return launch_fused_mt<6, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-            default: return launch_fused_mt<7, TW, 1, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
+            case 1: return launch_fused_mt<1, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 2: return launch_fused_mt<2, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 3: return launch_fused_mt<3, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 4: return launch_fused_mt<4, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 5: return launch_fused_mt<5, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 6: return launch_fused_mt<6, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            default: return launch_fused_mt<7, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
         }
     }
     const int ngrp = (tiles + 13) / 14;
     const int mt = ((tiles + ngrp - 1) / ngrp + 1) / 2;  // row tiles per slab
     switch (mt) {
-        case 4: return launch_fused_mt<4, TW, 2, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-        case 5: return launch_fused_mt<5, TW, 2, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-        case 6: return launch_fused_mt<6, TW, 2, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
-        default: return launch_fused_mt<7, TW, 2, F16, 1, HIN, HOUT>(x, packed, y, B, M, K, G, dbg, s);
+        case 4: return launch_fused_mt<4, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+        case 5: return launch_fused_mt<5, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+        case 6: return launch_fused_mt<6, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+        default: return launch_fused_mt<7, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
     }
 }
 

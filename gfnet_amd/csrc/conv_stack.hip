@@ -48,6 +48,17 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const float *__restrict
         } else if (i < d.wt16_off()) {
             const int m = (int)(i - d.bias_off());
             if (m < M) v = pw_b[m];
+        } else if (i >= d.mm_off()) {  // matrix-core depthwise parameters of a channel pair (PackDims::mm_off)
+            const int pair = (int)((i - d.mm_off()) / kMM2), j = (int)((i - d.mm_off()) % kMM2);
+            if (j < 80) {
+                const int ch = j / 40, dy = (j % 40) >> 3, dx = j & 7, k = 2 * pair + ch;
+                _Float16 h[2] = {(_Float16)0.f, (_Float16)0.f};
+                if (dx < 5 && k < C) h[ch] = (_Float16)dw_w[(size_t)k * 25 + dy * 5 + dx];
+                __builtin_memcpy(&v, h, 4);
+            } else if (j < 86) {
+                const int k = 2 * pair + (j & 1), t = (j - 80) >> 1;
+                if (k < C) v = t == 0 ? (dw_b ? dw_b[k] : 0.f) : t == 1 ? alpha[k] : beta[k];
+            }
         } else {  // invert wt16_index for the two halfs of this slot
             _Float16 h[2];
             for (int e2 = 0; e2 < 2; ++e2) {

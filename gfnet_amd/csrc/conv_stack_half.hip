@@ -10,13 +10,16 @@
 
 namespace {
 
-template <bool HIN, bool HOUT>
+// GFN_CONV_VALU_DW (environment, experiments): the depthwise on the VALU (fp32 taps) instead of the matrix core
+static const bool g_valu_dw = getenv("GFN_CONV_VALU_DW") != nullptr;
+
+template <bool HIN, bool HOUT, bool MM>
 int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, int dbg, hipStream_t s) {
     const float *xf = (const float *)x;
     float *yf = (float *)y;
-    if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
-    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
-    return launch_fused<8, true, HIN, HOUT>(xf, packed, yf, B, M, C, G, dbg, s);
+    if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
+    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
+    return launch_fused<8, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
 }
 
 }  // namespace
@@ -38,7 +41,12 @@ GFN_EXPORT int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *
     if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: C*G*G must fit 31 bits");
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == GFN_F32) return launch_half<false, true>(x, packed, y, B, C, M, G, dbg, s);
-    if (y_dtype == GFN_F32) return launch_half<true, false>(x, packed, y, B, C, M, G, dbg, s);
-    return launch_half<true, true>(x, packed, y, B, C, M, G, dbg, s);
+    if (g_valu_dw) {
+        if (x_dtype == GFN_F32) return launch_half<false, true, false>(x, packed, y, B, C, M, G, dbg, s);
+        if (y_dtype == GFN_F32) return launch_half<true, false, false>(x, packed, y, B, C, M, G, dbg, s);
+        return launch_half<true, true, false>(x, packed, y, B, C, M, G, dbg, s);
+    }
+    if (x_dtype == GFN_F32) return launch_half<false, true, true>(x, packed, y, B, C, M, G, dbg, s);
+    if (y_dtype == GFN_F32) return launch_half<true, false, true>(x, packed, y, B, C, M, G, dbg, s);
+    return launch_half<true, true, true>(x, packed, y, B, C, M, G, dbg, s);
 }

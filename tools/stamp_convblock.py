@@ -14,7 +14,8 @@ packed = ops.conv_block_pack(torch.randn(C, 25, device="cuda") * 0.2, torch.rand
                              torch.randn(C, device="cuda"), torch.randn(C, C, device="cuda") * C ** -0.5, torch.randn(C, device="cuda"))
 xh = torch.randn(B, (C + 1) // 2, G, G, 2, device="cuda").half()
 yh = torch.empty_like(xh)
-for m in (0, 0, 64):
+extra = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # more phases switched off (tools/ablate_convblock.py masks)
+for m in (extra, extra, 64 | extra):
     _lib.lib().gfn_conv_block_half_fwd(ptr(xh), (m << 8) | 1, ptr(packed), ptr(yh), 1, B, C, C, G, stream_ptr(xh.device))
     torch.cuda.synchronize()
 
