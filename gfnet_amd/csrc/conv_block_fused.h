@@ -53,6 +53,21 @@ struct PackDims {
 // output in (dy, dx) order, then (acc + bias) * alpha + beta, relu.
 __device__ __forceinline__ float dw_finish(float acc, float cb, float al, float be) { return fmaxf((acc + cb) * al + be, 0.f); }
 
+// buffer addressing for the staging loads: a scalar descriptor per map / parameter block and one 32-bit offset per lane (the
+// flat form cost ~15 VALU instructions of 64-bit address arithmetic per load: a quarter of a K tile's time in the wide blocks);
+// reads past the end of the descriptor return 0 (channel pairs past C in the last K tile)
+typedef __amdgpu_buffer_rsrc_t cb_rsrc_t;
+__device__ __forceinline__ cb_rsrc_t cb_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 cb_ld4(cb_rsrc_t r, unsigned voff) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float cb_ld(cb_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2 be) {
     f32x2 r;
@@ -182,11 +197,20 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     }
     unsigned l_item = w_begin;  // load stage: the (item, K tile) the next issue() fetches
     int l_kt = 0, l_m0 = 0, l_valid = 0;  // l_valid bit i: slot i lies inside the map (else zero padding)
-    const float *l_xb = x;
+    const unsigned map_bytes = (unsigned)(HIN ? (K + 1) / 2 : K) * (unsigned)plane * 4u;  // HIN: dwords = half2 cells
+    cb_rsrc_t x_rsrc = cb_rsrc(x, map_bytes);
+    unsigned av[APT > 0 ? APT : 1];  // byte offsets of this thread's weight-tile pieces inside a K tile's block
     auto load_stage_enter_item = [&]() {
         int b, row0, col0;
         decode(l_item, b, row0, col0, l_m0);
-        l_xb = x + (size_t)b * (HIN ? (K + 1) / 2 : K) * plane;  // HIN: dwords = half2 cells
+        x_rsrc = cb_rsrc(x + (size_t)b * (HIN ? (K + 1) / 2 : K) * plane, map_bytes);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e = tid + NT * i;
+            const int g = e / BMS, m = l_m0 + e - g * BMS;
+            const bool ok = e < AV4 && m < Mp;
+            av[i] = (unsigned)((ok ? g : 0) * Mp + (ok ? m : 0)) * 16u;
+        }
         l_valid = 0;
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
@@ -195,7 +219,8 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             const int hr = rem / RV4, q = rem - hr * RV4;
             const int gy = row0 - 2 + hr, gx = col0 - 4 + 4 * q;
             const bool ok = e < PS && (unsigned)gy < (unsigned)G && gx >= 0 && gx < G;  // G % 4 == 0: 4 cells in or out together
-            xg[i] = ok ? gy * G + gx : 0;
+            // byte offset inside the map of this slot's piece in the K tile's first channel pair (HIN) / channel
+            xg[i] = ((ok ? gy * G + gx : 0) + (HIN ? xp2[i] >> 1 : xp2[i]) * plane) * 4;
             l_valid |= ok ? 1 << i : 0;
         }
     };
@@ -210,37 +235,27 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     int r_valid = 0;  // l_valid of the item in the registers; bit 8: its first K tile (refresh the zero padding); bit 9: a first K
                       // tile (file the bias), bit 10: the item's parity
     float bias_r = 0.f;
-    const float4 *wt4 = reinterpret_cast<const float4 *>(F16 ? packed + pd.wt16_off() : wt);
-    auto a_load = [&](int kt, int i) {
-        const int e = tid + NT * i;
-        const int g = e / BMS, m = l_m0 + e - g * BMS;
-        const bool ok = e < AV4 && m < Mp;
-        return wt4[(size_t)(kt * GP + (ok ? g : 0)) * Mp + (ok ? m : 0)];
-    };
+    const cb_rsrc_t a_rsrc = cb_rsrc(F16 ? packed + pd.wt16_off() : wt, (unsigned)Kp * (unsigned)Mp * (F16 ? 2u : 4u));
+    const cb_rsrc_t p_rsrc = cb_rsrc(cp, (unsigned)(Kp / 2) * PW * 4u);
+    auto a_load = [&](int kt, int i) { return cb_ld4(a_rsrc, av[i] + (unsigned)(kt * GP * Mp) * 16u); };
     auto a_store = [&](int buf, int i, const float4 &v) {
         const int e = tid + NT * i;
         if (e < AV4) As4[buf][e] = v;
     };
     auto issue = [&]() {  // fetch (l_item, l_kt) into registers, advance the load stage
         if (dbg & 1) return;
-        const int k0 = l_kt * kKT;
+        const unsigned kx = (unsigned)l_kt * (unsigned)((HIN ? kNP : kKT) * plane) * 4u;  // the K tile's first pair / channel
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
-            if constexpr (HIN) {  // one 16-byte load = 4 cells of a channel pair
-                const int pp = min((k0 + xp2[i]) >> 1, ((K + 1) >> 1) - 1);
-                xr0[i] = *reinterpret_cast<const float4 *>(l_xb + pp * plane + xg[i]);
-            } else {
-                const int c0 = min(k0 + xp2[i], K - 1), c1 = min(k0 + xp2[i] + 1, K - 1);  // past C: any finite data, its taps are 0
-                xr0[i] = *reinterpret_cast<const float4 *>(l_xb + c0 * plane + xg[i]);
-                xr1[i] = *reinterpret_cast<const float4 *>(l_xb + c1 * plane + xg[i]);
-            }
+            xr0[i] = cb_ld4(x_rsrc, (unsigned)xg[i] + kx);  // HIN: 4 cells of a channel pair; past C: zeros (their taps are 0 too)
+            if constexpr (!HIN) xr1[i] = cb_ld4(x_rsrc, (unsigned)xg[i] + kx + (unsigned)plane * 4u);
         }
         if constexpr (APT > 0) ar0 = a_load(l_kt, 0);
         if constexpr (APT > 1) ar1 = a_load(l_kt, 1);
         if constexpr (APT > 2) ar2 = a_load(l_kt, 2);
         if constexpr (APT > 3) ar3 = a_load(l_kt, 3);
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) pr[i] = cp[(size_t)(k0 / 2) * PW + min(tid + NT * i, kNP * PW - 1)];
+        for (int i = 0; i < PPT; ++i) pr[i] = cb_ld(p_rsrc, (unsigned)(l_kt * kNP * PW + min(tid + NT * i, kNP * PW - 1)) * 4u);
         r_valid = l_valid | (l_kt == 0 && l_item != w_begin ? 256 : 0);
         if (l_kt == 0) {
             r_valid |= 512 | (((l_item - w_begin) & 1u) ? 1024 : 0);
@@ -602,7 +617,8 @@ int launch_fused(const float *x, const float *packed, float *y, int B, int M, in
             }
         }
     }
-    if (tiles <= 7) {
+    static const bool ns1 = getenv("GFN_CONV_NS1") != nullptr;  // experiments: one slab per workgroup, two workgroups per cell tile
+    if (tiles <= 7 || ns1) {
         switch (tiles) {
             case 1: return launch_fused_mt<1, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
             case 2: return launch_fused_mt<2, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);

@@ -262,7 +262,7 @@ GFN_EXPORT int gfn_conv_block_fwd(const float *x, const float *packed, float *y,
     if (x == y) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: in-place is not supported (cells read their neighbours)");
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
-    if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: C*G*G must fit 31 bits");
+    if ((long)C * G * G > 0x1fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: a map (C*G*G floats) must stay below 2 GB");
     const int dbg = variant >> 8;  // ablation mask, honoured by -DGFN_ABLATE builds only
 #ifdef GFN_ABLATE
     variant &= 0xff;

@@ -12,13 +12,14 @@ namespace {
 
 // GFN_CONV_VALU_DW (environment, experiments): the depthwise on the VALU (fp32 taps) instead of the matrix core
 static const bool g_valu_dw = getenv("GFN_CONV_VALU_DW") != nullptr;
+static const int g_tw16_min = getenv("GFN_CONV_TW16_MIN") ? atoi(getenv("GFN_CONV_TW16_MIN")) : 0;
 
 template <bool HIN, bool HOUT, bool MM>
 int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, int dbg, hipStream_t s) {
     const float *xf = (const float *)x;
     float *yf = (float *)y;
     if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
-    if (G % 16 == 0 || G > 64) return launch_fused<16, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
+    if (G % 16 == 0 || G > (g_tw16_min ? g_tw16_min : 64)) return launch_fused<16, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
     return launch_fused<8, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
 }
 
@@ -38,7 +39,7 @@ GFN_EXPORT int gfn_conv_block_half_fwd(const void *x, int x_dtype, const float *
         return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: fp32 in and out is gfn_conv_block_fwd (variant 2)");
     if (x == y) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: in-place is not supported (cells read their neighbours)");
     if (G & 3) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: grid side must be a multiple of 4 (got %d)", G);
-    if ((long)C * G * G > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: C*G*G must fit 31 bits");
+    if ((long)C * G * G > 0x1fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block_half: a map (C*G*G elements) must stay below 2 GB");
     if (B == 0) return GFN_OK;
     hipStream_t s = (hipStream_t)stream;
     if (g_valu_dw) {

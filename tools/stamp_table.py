@@ -11,8 +11,9 @@ for t in range(5):
     names.update({3 + 6 * t: f"commit{t}", 4 + 6 * t: f"barrier{t}a", 5 + 6 * t: f"issue{t}", 6 + 6 * t: f"dw{t}", 7 + 6 * t: f"barrier{t}b", 8 + 6 * t: f"mfma{t}"})
 agg = collections.defaultdict(list)
 tot = []
+late = any(k[0] >= 1000 for k in rows)
 for key, st in rows.items():
-    if key[0] < 1000:
+    if late and key[0] < 1000:
         continue  # first round of workgroups: cold instruction cache
     idx = [i for i in sorted(st) if i < 33]
     prev = 0
