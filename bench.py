@@ -9,15 +9,17 @@ already resident in HBM:
   upsample_preds, attenuate_cert) -> match post-processing -> balanced sampling (2 draws without
   replacement + KDE, N=M=20000) -> device RANSAC/DLT/LM homography solve -> (N>1) RCCL all-gather of H.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 448b32|672b16|pyr-fp16] [--conv-stack off|fp32|fp16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 448b32|672b16|pyr-fp16] [--conv-stack off|fp32|fp16|amp]
 
 Workloads (BASELINE.json configs):
   448b32   (default, configs[1]) 448x448, 32 pairs per GPU, basic.json (num_itr 1), fp32 features
   672b16   (configs[2]) googlemap 672x672, 16 pairs per GPU, map.json (num_itr 2 per scale), grids by the rule of
            network.py:329 ([S/14, S/14, 2S/14, 4S/14, 8S/14] = 48/48/96/192/384, refinement pass at 840)
   pyr-fp16 (configs[4]) feature pyramids stored in fp16 at the 224 / 448 / 672 test-set sizes, 8 pairs each per step
-The refiners' conv stacks are a stand-in by default (`config.excluded`); `--conv-stack fp32|fp16`
-runs the reference's architecture on the HIP conv-stack kernels inside the timed region.
+The refiners' conv stacks are a stand-in by default (`config.excluded`); `--conv-stack fp32|fp16|amp`
+runs the reference's architecture on the HIP conv-stack kernels inside the timed region (fp32: fp32 throughout; fp16: fp16
+operands of the 1x1 convs; amp: fp16 operands and fp16 maps between the blocks -- the class the reference's amp=True refiners
+run in, model/network.py:560-562).
 
 Prints ONE JSON line on rank 0 (driver contract).  `roofline` is for the dominant kernel of the named config, the scale-4
 local-correlation call of the first pass (c32, r=4), timed with HIP events on its launch stream inside the timed steps;
@@ -405,16 +407,22 @@ def main():
                    "symmetric": True, "upsample_pass": "1.25x (560 at 448)", "attenuate_cert": True,
                    "flow_noise": f"stand-in increment = true warp + N(0,({FLOW_NOISE_PX}/S)^2) - flow, fresh realisation per iteration",
                    "stages": "corr_softargmax, (refiner_input + local_corr + flow_update) x scales x num_itr for both passes, resize, "
-                             "match_post, sample(2 draws without replacement + KDE 20000^2), RANSAC(2000)+DLT+LM, H all-gather",
+                             "match_post, sample(2 draws without replacement + KDE 20000^2), RANSAC(<= 2000 hypotheses, OpenCV's confidence-0.99999 "
+                             "bound)+DLT+LM, H all-gather",
                    "excluded": ("DINOv2/FPN backbone; refiner conv stacks replaced by the stand-in increment (1 torch elementwise op per "
-                                "refiner call; --conv-stack fp32|fp16 runs them on the HIP conv-stack kernels)") if args.conv_stack == "off"
+                                "refiner call; --conv-stack fp32|fp16|amp runs them on the HIP conv-stack kernels)") if args.conv_stack == "off"
                    else "DINOv2/FPN backbone (PyTorch-ROCm host code)",
                    "refiner_conv_stack": "off" if args.conv_stack == "off" else
                    f"reference architecture (9 dw5x5+BN+ReLU+1x1 blocks + out conv per refiner call, C=417/361/177/73/24), random-init, "
-                   f"HIP conv_stack kernels, 1x1 operands {args.conv_stack}; output weighted 0 next to the stand-in increment",
+                   f"HIP conv_stack kernels, " + {"fp32": "fp32 throughout", "fp16": "1x1 operands fp16, maps fp32",
+                                               "amp": "fp16 maps between the blocks, depthwise and 1x1 operands fp16, fp32 accumulation "
+                                                      "(the reference's autocast class)"}[args.conv_stack] +
+                   "; output weighted 0 next to the stand-in increment",
                    "parallelism": f"pairs sharded over {world} GPU(s), RCCL all-gather of H only"},
         "roofline": {"bound": "hbm",
-                     "kernel": f"gfn_local_corr_fwd call (plan + lean tile kernel + second launch; c32, {hs4}x{hs4}, G{G4}, r4, {2 * B} directions)",
+                     "kernel": f"gfn_local_corr_fwd_dt call (lean tile kernel, its first workgroups finish the tiles the plan left to "
+                               f"the second launch; the plan itself is written by the refiner_input launch; c32, {hs4}x{hs4}, G{G4}, r4, "
+                               f"{2 * B} directions)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(kern_us, 2), "calls_per_step": n_calls,

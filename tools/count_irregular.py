@@ -1,39 +1,30 @@
-"""How many tiles of each local-correlation call of the bench step go to the irregular (second) launch."""
-import ctypes
+"""Per local-correlation call of one bench step: tiles left to the second launch, cells redone tap by tap, tiles staged in two
+halves -- the counters the kernels leave in the scratch header (csrc/local_corr.hip kTodoHdr), read through ops.kernel_counters.
+usage (GPU box): python tools/count_irregular.py [bench args, e.g. --workload 672b16]"""
 import os
 import sys
-
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from gfnet_amd import _lib  # noqa: E402
+from gfnet_amd import ops  # noqa: E402
 
-L = _lib.lib()
-orig = L.gfn_local_corr_fwd
-seen = []
-
-
-def wrapped(*a):
-    rc = orig(*a)
-    torch.cuda.synchronize()
-    B, C, G, H, W, r = (int(getattr(v, "value", v)) for v in a[7:13])
-    scratch = a[16]
-    n = ctypes.cast(scratch, ctypes.POINTER(ctypes.c_int))
-    cnt = torch.empty(1, dtype=torch.int32)
-    import ctypes as ct
-    hip = ct.CDLL("libamdhip64.so")
-    buf = ct.c_int(0)
-    hip.hipMemcpy(ct.byref(buf), ct.c_void_p(getattr(scratch, 'value', scratch) + 12), 4, 2)  # int 3: the last call's count
-    rounds = 2 if r <= 4 else 1
-    tiles = B * ((G + 15) // 16) * ((G + 2 * rounds - 1) // (2 * rounds))
-    seen.append((C, H, G, r, buf.value, tiles))
-    return rc
-
-
-L.gfn_local_corr_fwd = wrapped
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--cpu-pairs", "0"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--cpu-pairs", "0"] + sys.argv[1:]
 bench.main()
-for C, H, G, r, cnt, tiles in seen[:7]:
-    print(f"c{C} hs{H} G{G} r{r}: {cnt} of {tiles} tiles irregular ({100.0*cnt/tiles:.1f} %)")
+ops.kernel_counters = {}
+real_stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+try:
+    bench.main()  # one more step with the counters collected (a device sync per call)
+finally:
+    sys.stdout = real_stdout
+for name, rows in ops.kernel_counters.items():
+    # name = local_corr_c{C}_h{Hs}_g{G}_r{r}
+    f = dict((p[0], int(p[1:])) for p in name.split("_")[2:])
+    rounds = 2 if f["r"] <= 4 else 1
+    tiles_per_dir = ((f["g"] + 15) // 16) * ((f["g"] + 2 * rounds - 1) // (2 * rounds))
+    n = len(rows)
+    second = sum(r[0] for r in rows) / n
+    flagged = sum(r[1] for r in rows) / n
+    halves = sum(r[2] for r in rows) / n
+    print(f"{name}: {n} calls; per call {second:.1f} tiles to the second launch, {flagged:.1f} cells redone per tap, "
+          f"{halves:.1f} (sampled) tiles staged in halves; {tiles_per_dir} tiles per direction")

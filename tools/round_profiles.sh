@@ -15,5 +15,6 @@ print('$NAME', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline'
 run 448b32
 run 672b16 --workload 672b16
 run pyr_fp16 --workload pyr-fp16
+run 448b32_convstack_amp --conv-stack amp
 run 448b32_convstack_fp16 --conv-stack fp16
 run 448b32_convstack_fp32 --conv-stack fp32
