@@ -1,30 +1,24 @@
 """Per local-correlation call of one bench step: tiles left to the second launch, cells redone tap by tap, tiles staged in two
-halves -- the counters the kernels leave in the scratch header (csrc/local_corr.hip kTodoHdr), read through ops.kernel_counters.
+halves (sampled) -- the counters the kernels leave in the scratch header (csrc/local_corr.hip kTodoHdr), which bench.py
+--breakdown collects through ops.kernel_counters.
 usage (GPU box): python tools/count_irregular.py [bench args, e.g. --workload 672b16]"""
+import ast
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from gfnet_amd import ops  # noqa: E402
-
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--cpu-pairs", "0"] + sys.argv[1:]
-bench.main()
-ops.kernel_counters = {}
-real_stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
-try:
-    bench.main()  # one more step with the counters collected (a device sync per call)
-finally:
-    sys.stdout = real_stdout
-for name, rows in ops.kernel_counters.items():
-    # name = local_corr_c{C}_h{Hs}_g{G}_r{r}
-    f = dict((p[0], int(p[1:])) for p in name.split("_")[2:])
+cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--breakdown"] + sys.argv[1:]
+err = subprocess.run(cmd, capture_output=True, text=True).stderr
+for line in err.splitlines():
+    if not line.startswith("[counters] "):
+        continue
+    name, rest = line[len("[counters] "):].split(":", 1)
+    rows = ast.literal_eval(rest.split(":", 1)[1].strip())
+    f = dict((p[0], int(p[1:])) for p in name.split("_")[2:])  # local_corr_c{C}_h{Hs}_g{G}_r{r}
     rounds = 2 if f["r"] <= 4 else 1
-    tiles_per_dir = ((f["g"] + 15) // 16) * ((f["g"] + 2 * rounds - 1) // (2 * rounds))
+    tiles = ((f["g"] + 15) // 16) * ((f["g"] + 2 * rounds - 1) // (2 * rounds))
     n = len(rows)
-    second = sum(r[0] for r in rows) / n
-    flagged = sum(r[1] for r in rows) / n
-    halves = sum(r[2] for r in rows) / n
-    print(f"{name}: {n} calls; per call {second:.1f} tiles to the second launch, {flagged:.1f} cells redone per tap, "
-          f"{halves:.1f} (sampled) tiles staged in halves; {tiles_per_dir} tiles per direction")
+    print(f"{name}: {n} call(s) per step; per call {sum(r[0] for r in rows) / n:.1f} tiles to the second launch, "
+          f"{sum(r[1] for r in rows) / n:.1f} cells redone per tap, {sum(r[2] for r in rows) / n:.1f} tiles staged in halves (sampled); "
+          f"{tiles} tiles per direction")
