@@ -84,8 +84,8 @@ __device__ __forceinline__ CellBox cell_box(bool ok, float nx, float ny, float x
 struct RowPlan {  // block-uniform (scalars)
     int x0, y0, w, h, pitch;
     int nq;       // 16-byte quads per region row
-    int rpi;      // region rows per work item (<= 64 / nq)
-    int nitems;   // (row group, channel quad) pairs of a 16-channel chunk: a multiple of 8, nitems / 8 per wave
+    int nitems;   // work items of a 16-channel chunk (16 consecutive quads of the region, row major, x 4 channel quads): a
+                  // multiple of 8, nitems / 8 per wave
 };
 
 template <int R>
@@ -96,13 +96,9 @@ __device__ __forceinline__ bool region_fits(RowPlan &u) {
     u.pitch = w4 + ((PW - w4) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
     if ((long)u.pitch * u.h > Lean<R>::kCap && (long)w4 * u.h <= Lean<R>::kCap) u.pitch = w4;
     if ((long)u.pitch * u.h > Lean<R>::kCap || u.w > 64) return false;
-    // row groups: an even number of them, so that the 4 * groups work items of a chunk split evenly over the 8 waves
-    // (every wave issues the same number of loads: no branches around loads, exact wait counts)
-    const int rpi_max = u.nq > 0 ? 64 / u.nq : 64;
-    int ng = (u.h + rpi_max - 1) / rpi_max;
-    ng = (ng + 1) & ~1;
-    u.rpi = ng > 0 ? (u.h + ng - 1) / ng : 1;
-    u.nitems = ng * 4;
+    // a multiple of 8 items, so that they split evenly over the 8 waves (every wave issues the same number of loads: no
+    // branches around loads, exact wait counts)
+    u.nitems = ((u.h * u.nq + 15) / 16 + 7) & ~7;
     return true;
 }
 
@@ -249,58 +245,85 @@ __device__ __forceinline__ void buf_st_nt(rsrc_t r, unsigned voff, unsigned soff
 }
 
 // ---- staging: 16-byte quads along the row --------------------------------------------------------------------------
-// Work item it (of a 16-channel chunk) = (row group it >> 2, channel quad it & 3); wave w takes items w, w + 8, ...  A lane
-// owns quad `q` of region row `rg * rpi + ry` (ry = lane / nq, q = lane % nq): four loads (one per channel plane of the
-// quad) bring 4 pixels x 4 channels, which leave as four 16-byte slot writes (pixel-major [pixel][16 channels + pad]).
+// Work item it (of a 16-channel chunk) = quads 16 it .. 16 it + 15 of the region in row-major order, all four channel quads;
+// wave w takes items w, w + 8, ...  Lane bits 0-1 and 4-5 = the quad, bits 2-3 = the channel quad cg: four loads (one per
+// channel plane of the channel quad) bring 4 pixels x 4 channels, which leave as four 16-byte slot writes (pixel-major
+// [pixel][16 channels + pad]).  The bank of a slot write is 4 * quad + 5 * pixel + cg (mod 16, in 16-byte units): sixteen
+// lanes of one channel quad hit only four bank groups (measured with all 64 lanes on one channel quad: 30 % of the LDS-active
+// cycles of the tile kernel were bank conflicts, all of them these writes); four consecutive quads x four channel quads hit
+// sixteen.  Four consecutive lanes still read 64 contiguous bytes of one plane (with cg on the lowest lane bits the texture
+// path saw four cache lines per lane quad and the op went from 105 to 120 us).
 template <int N, typename FT>
 struct QuadRegs {
     typename QuadRaw<FT>::type a[N][4];  // [item][channel of the quad] -> 4 pixels, as loaded (fp16 is widened at the commit)
 };
 
-struct QuadLane {         // per lane, constant for the tile
-    unsigned voff;        // byte offset (in the map's storage type) of the lane's quad inside an image plane, relative to the region's first row group
-    int slot;             // float4 index of the lane's first pixel slot, relative to the row group and channel quad
-    int ry;               // region row inside a row group (>= rpi: lane idle)
-    unsigned xmask;       // CHECK: bit k set = pixel k of the quad lies inside the image
+constexpr int kQuadPre = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
+struct QuadItem {
+    unsigned voff;        // byte offset of the lane's quad: (row * W + x) elements + the channel quad's four planes
+    unsigned meta;        // bits 0-11: float4 index of the lane's first pixel slot (+ cg); 12-15: pixels of the quad inside the
+                          // image (CHECK); 16: the lane has a quad in this item; 17: its row lies inside the image (CHECK)
 };
+struct QuadLane {         // per lane and region, the first kQuadPre items of this wave
+    QuadItem it[kQuadPre];
+};
+
+// item k of wave `wave`: where the lane's quad comes from and where it goes
+template <bool CHECK, typename FT>
+__device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, int wave, int lane, int k) {
+    constexpr unsigned ES = sizeof(FT);
+    const int cg = (lane >> 2) & 3;
+    const int L = (wave + 8 * k) * 16 + ((lane & 3) | ((lane >> 4) << 2));  // quad of the region, row major
+    const float inv_nq = __builtin_amdgcn_rcpf((float)max(u.nq, 1));
+    int row = (int)(((float)L + 0.5f) * inv_nq);      // L / nq, exact for these sizes (L < 1024)
+    int q = L - row * u.nq;
+    const bool have = row < u.h;
+    if (!have) row = 0, q = 0;                        // idle lanes repeat the region's first quad (a valid address)
+    const int x = u.x0 + 4 * q;
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xmask |= ((unsigned)(x + j) < (unsigned)W ? 1u : 0u) << j;
+    const int gy = u.y0 + row;
+    const bool row_in = (unsigned)gy < (unsigned)H;
+    QuadItem o;
+    // border tiles: x0 is a multiple of 4 (plan launch), so a quad never straddles the left image edge; quads left of the image
+    // and rows outside it point at a pixel inside and are zeroed at the commit, like the pixels that hang over the right edge
+    const int px = CHECK ? (row_in ? gy : 0) * W + max(x, 0) : row * W + x;  // !CHECK: relative to the region's first row
+    o.voff = (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES;
+    o.meta = (unsigned)((row * u.pitch + 4 * q) * kSlotV4 + cg) | (xmask << 12) | (have ? 1u << 16 : 0u) | (row_in ? 1u << 17 : 0u);
+    return o;
+}
 
 template <int N, bool CHECK, typename FT>
 __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
-                                           const QuadLane &ql, int k0) {
+                                           int lane, const QuadLane &ql, int k0) {
     constexpr unsigned ES = sizeof(FT);
     const unsigned plane4 = (unsigned)(H * W) * ES;  // bytes of a channel plane
     const int ipw = u.nitems >> 3;  // items per wave
+    // every staged row of an unchecked tile lies inside the image: its first row goes into the scalar offset
+    const unsigned so = chunk_off + (CHECK ? 0u : (unsigned)(u.y0 * W) * ES);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-        // no branch around the loads: an item past the wave's last one repeats it (same addresses: L1 hits, result unused)
-        const int it = wave + 8 * max(min(k0 + n, ipw - 1), 0);   // scalar
-        const int cg = it & 3, row0 = (it >> 2) * u.rpi;          // scalars
-        unsigned so = chunk_off + (unsigned)cg * 4u * plane4, vo;
-        if (!CHECK) {
-            so += (unsigned)((u.y0 + row0) * W) * ES;             // every staged row lies inside the image
-            vo = ql.voff;
-        } else {
-            // rows may lie outside the image (then the scalar row offset could be negative): the row goes into the
-            // per-lane offset, lanes of outside rows point at pixel 0 and are zeroed at the commit
-            const int gy = u.y0 + row0 + ql.ry;
-            vo = (unsigned)gy < (unsigned)H ? ql.voff + (unsigned)((u.y0 + row0) * W) * ES : 0u;
-        }
+        // no branch around the loads: an item past the wave's last one repeats the last one (L1 hits, result unused)
+        unsigned vo;
+        if (k0 == 0 && n < kQuadPre) vo = (n == 0 || n < ipw) ? ql.it[n].voff : ql.it[0].voff;
+        else vo = quad_item<CHECK, FT>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
     }
 }
 
 template <int N, bool CHECK, typename FT>
-__device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r, int H, const RowPlan &u, int wave, const QuadLane &ql, int k0) {
+__device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r, int H, int W, const RowPlan &u, int wave, int lane,
+                                            const QuadLane &ql, int k0) {
     const int ipw = u.nitems >> 3;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-        const int it = wave + 8 * (k0 + n);
-        const int cg = it & 3, row0 = (it >> 2) * u.rpi;
-        if ((k0 + n < ipw) & (ql.ry < u.rpi) & (row0 + ql.ry < u.h)) {
-            float4 *dst = s4 + (ql.slot + row0 * u.pitch) * kSlotV4 + cg;
+        const unsigned meta = (k0 == 0 && n < kQuadPre) ? ql.it[n].meta : quad_item<CHECK, FT>(u, H, W, wave, lane, k0 + n).meta;
+        if ((k0 + n < ipw) & ((meta >> 16) & 1u)) {
+            float4 *dst = s4 + (meta & 0xFFFu);
             unsigned m = 0xFu;
-            if (CHECK) m = (unsigned)(u.y0 + row0 + ql.ry) < (unsigned)H ? ql.xmask : 0u;
+            if (CHECK) m = ((meta >> 17) & 1u) ? (meta >> 12) & 0xFu : 0u;
             const f32x4 w0 = QuadRaw<FT>::widen(r.a[n][0]), w1 = QuadRaw<FT>::widen(r.a[n][1]), w2 = QuadRaw<FT>::widen(r.a[n][2]),
                         w3 = QuadRaw<FT>::widen(r.a[n][3]);
 #pragma unroll
@@ -314,12 +337,12 @@ __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r
 }
 
 template <bool CHECK, typename FT>
-__device__ __forceinline__ void quad_rest(float4 *s4, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
+__device__ __forceinline__ void quad_rest(float4 *s4, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave, int lane,
                                           const QuadLane &ql, int done) {
-    for (int k0 = done; k0 < (u.nitems >> 3); ++k0) {  // only regions taller than two row groups per wave pair (rare)
+    for (int k0 = done; k0 < (u.nitems >> 3); ++k0) {  // only regions of more than 256 quads (rare)
         QuadRegs<1, FT> r;
-        quad_issue<1, CHECK, FT>(r, f1r, chunk_off, H, W, u, wave, ql, k0);
-        quad_commit<1, CHECK, FT>(s4, r, H, u, wave, ql, k0);
+        quad_issue<1, CHECK, FT>(r, f1r, chunk_off, H, W, u, wave, lane, ql, k0);
+        quad_commit<1, CHECK, FT>(s4, r, H, W, u, wave, lane, ql, k0);
     }
 }
 
@@ -406,23 +429,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
     auto quad_lane = [&](const RowPlan &u) {
         QuadLane ql;
-        const float inv_nq = __builtin_amdgcn_rcpf((float)max(u.nq, 1));
-        ql.ry = (int)(((float)lane + 0.5f) * inv_nq);  // lane / nq, exact for these sizes
-        const int q = lane - ql.ry * u.nq;
-        ql.slot = ql.ry * u.pitch + 4 * q;
-        ql.xmask = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ql.xmask |= ((unsigned)(u.x0 + 4 * q + k) < (unsigned)W ? 1u : 0u) << k;
-        // border tiles: x0 is a multiple of 4 (plan launch), so a quad never straddles the left image edge; quads left of the
-        // image point at column 0 and are zeroed by the mask, like the pixels of a quad that hangs over the right edge
-        ql.voff = (unsigned)(ql.ry * W + (CHECK ? max(u.x0 + 4 * q, 0) : u.x0 + 4 * q)) * (unsigned)sizeof(FT);
+        for (int n = 0; n < kQuadPre; ++n) ql.it[n] = quad_item<CHECK, FT>(u, H, W, wave, lane, n);
         return ql;
     };
     const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
-    constexpr int PRE = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
+    constexpr int PRE = kQuadPre;
     QuadRegs<PRE, FT> pre;
-    quad_issue<PRE, CHECK, FT>(pre, f1r, 0u, H, W, uA, wave, qlA, 0);
+    quad_issue<PRE, CHECK, FT>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
@@ -462,8 +477,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int k = 0; k < NF0; ++k) f0s[fcell * CS + wave + k * kWaves] = fok ? f0v[k] : 0.f;
     }
     STAMP(2);
-    quad_commit<PRE, CHECK, FT>(s4, pre, H, uA, wave, qlA, 0);
-    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, qlA, PRE);
+    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
+    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -514,7 +529,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) quad_issue<PRE, CHECK, FT>(pre, f1r, next_off, H, W, un, wave, qn, 0);  // next step's loads: in flight across this D-stage
+        if (more) quad_issue<PRE, CHECK, FT>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);  // next step's loads: in flight across this D-stage
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
@@ -546,8 +561,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (more) {
             __syncthreads();  // everyone is done reading this step's pixels
             STAMP(7);
-            quad_commit<PRE, CHECK, FT>(s4, pre, H, un, wave, qn, 0);
-            quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, qn, PRE);
+            quad_commit<PRE, CHECK, FT>(s4, pre, H, W, un, wave, lane, qn, 0);
+            quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
             __syncthreads();
             STAMP(8);
         }
