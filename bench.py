@@ -19,7 +19,8 @@ Workloads (BASELINE.json configs):
 The refiners' conv stacks are a stand-in by default (`config.excluded`); `--conv-stack fp32|fp16|amp`
 runs the reference's architecture on the HIP conv-stack kernels inside the timed region (fp32: fp32 throughout; fp16: fp16
 operands of the 1x1 convs; amp: fp16 operands and fp16 maps between the blocks -- the class the reference's amp=True refiners
-run in, model/network.py:560-562).
+run in, model/network.py:560-562).  A default single-GPU run also reports that last figure as `with_conv_stacks` next to
+`value` (secondary measurement after the timed region; --no-stack-leg skips it).
 
 Prints ONE JSON line on rank 0 (driver contract).  `roofline` is for the dominant kernel of the named config, the scale-4
 local-correlation call of the first pass (c32, r=4), timed with HIP events on its launch stream inside the timed steps;
@@ -301,6 +302,9 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="override the workload's pairs per GPU (per size)")
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs per size for the CPU-oracle baseline leg (0 = skip; default: per workload)")
     ap.add_argument("--breakdown", action="store_true", help="print per-stage GPU times of one step to stderr")
+    ap.add_argument("--no-stack-leg", action="store_true",
+                    help="skip the secondary measurement `with_conv_stacks` (default single-GPU runs with --conv-stack off also time the same "
+                         "step with the refiners' conv stacks in the reference's autocast class)")
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
@@ -369,6 +373,27 @@ def main():
             for name, cs in ops.kernel_counters.items():
                 print(f"[counters] {name}: second-launch tiles / flagged cells / half-staged tiles per call: {cs}", file=sys.stderr)
         ops.kernel_counters = None
+        # secondary figure: the same step with the refiners' real conv stacks (reference architecture, random-init)
+        # in the class the reference runs them in on a GPU -- `value` above replaces them by a one-op stand-in
+        stack_leg = None
+        if args.conv_stack == "off" and world == 1 and not args.no_stack_leg:
+            with torch.inference_mode(False):  # module parameters must be ordinary tensors (the packed-parameter cache reads their versions)
+                scenes2 = [Scene(S, B, wl["num_itr"], dtype, "amp", dev, rank) for S in wl["sizes"]]
+            for i in range(2):
+                for sc in scenes2:
+                    sc.step(i)
+            torch.cuda.synchronize()
+            n2 = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for i in range(n2):
+                for sc in scenes2:
+                    sc.step(0)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            stack_leg = {"value": round(pairs_per_step * n2 / dt2, 2), "unit": "pairs/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
+                         "refiner_conv_stack": "reference architecture, random-init, HIP conv_stack kernels, conv_precision='amp' (fp16 maps, "
+                                               "fp16 operands, fp32 accumulation: model/network.py:560-562)"}
+            del scenes2
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -439,6 +464,8 @@ def main():
         ace_o, ace_t = solve_parity(main_scene, outs[sc_i][1], outs[sc_i][0], min(2, B))
         out["mean_corner_error_vs_ref_px"] = ace_o
         out["mean_corner_error_vs_truth_px"] = ace_t
+    if stack_leg is not None:
+        out["with_conv_stacks"] = stack_leg
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

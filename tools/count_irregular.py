@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--breakdown"] + sys.argv[1:]
+cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-pairs", "0", "--breakdown", "--no-stack-leg"] + sys.argv[1:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 for line in err.splitlines():
     if not line.startswith("[counters] "):
