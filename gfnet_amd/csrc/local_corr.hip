@@ -354,8 +354,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     constexpr int P = PW * PW;               // patch positions per cell
     constexpr int NP = (P + 15) / 16;        // positions per lane
     constexpr int D = 2 * R + 1, K = D * D;
-    constexpr int TH = 2 * ROUNDS;           // tile height in cells
-    constexpr int NC = 32 * ROUNDS;          // cells per tile
+    constexpr int NC = 32 * ROUNDS;          // cells per tile (2 * ROUNDS rows of 16)
     constexpr int DS = P + 1;                // D-buffer cell stride (odd: conflict-free epilogue reads)
     constexpr int TS = 2 * D + 1;            // fraction-table cell stride (odd)
     // small windows (r <= 2, 16-channel maps) leave LDS for a fraction table of its own next to the stage: it is then filled
@@ -428,7 +427,6 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     int bx0 = kFar, by0 = kFar, bx1 = -kFar, by1 = -kFar;  // this cell's window clipped to the image
     bool inside = true;                                      // ... and whether clipping changed nothing
     if (tid < NC) {
-        const int gi = cell_gi(tid), gj = cell_gj(tid);
         int X0 = kFar, Y0 = kFar, slow = 0;
         float nx = 0.f, ny = 0.f;
         if (cell_ok(tid)) {

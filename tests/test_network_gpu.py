@@ -50,6 +50,24 @@ def test_g4_refiner_forward_matches_reference():
     assert_close(host(dflow1), g["delta_flow_nocorr"], 1e-4, "delta_flow (no corr)")
 
 
+@pytest.mark.parametrize("precision", ["fp16", "amp"])
+def test_g4_refiner_forward_in_the_autocast_classes(precision):
+    """The same golden through the reduced-precision conv stacks (`conv_precision`): 'fp16' rounds the 1x1 operands, 'amp' is the
+    class the reference's amp=True refiners run in on a GPU (fp16 maps between the blocks).  The golden was produced in fp32
+    on the CPU, so the yardstick is the fp16 rounding of nine chained blocks: a few 1e-3 of the output magnitude."""
+    g = load_golden("g4_refiner_prefix")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    ref = _toy_refiner(8, 6, int(g["r"]), int(g["hidden_blocks"]), sd)
+    ref.conv_precision = precision
+    with torch.no_grad():
+        dflow, dcert, lc = ref(int(g["G"]), dev(g["x"]), dev(g["y"]), dev(g["flow"]), scale_factor=float(g["scale_factor"]))
+    assert_close(host(lc), g["local_corr"], 1e-4, "local_corr")  # the correlation itself stays fp32
+    mag = max(float(np.abs(g["delta_flow"]).max()), float(np.abs(g["delta_cert"]).max()), 1.0)
+    assert float(np.abs(host(dflow) - g["delta_flow"]).max()) <= 1e-2 * mag
+    assert float(np.abs(host(dcert) - g["delta_cert"]).max()) <= 1e-2 * mag
+    assert dflow.dtype == torch.float32 and dcert.dtype == torch.float32
+
+
 def _g5_model(g):
     from gfnet_amd.model.network import GFNet
     import torch.nn as nn
