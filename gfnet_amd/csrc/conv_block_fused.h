@@ -96,7 +96,12 @@ __device__ __forceinline__ f32x2 dw_finish2(f32x2 acc, f32x2 cb, f32x2 al, f32x2
 // B = the band of one tap row (built per pair from a 6-entry table), accumulated over the 5 tap rows.  85 % of the products
 // are zeros, and it still costs a fifth of the VALU form (25 v_pk_fma_f32 per cell pair); BatchNorm + ReLU stay fp32 on the
 // accumulator.  Taps rounded to fp16 (torch.autocast does the same to the conv weight).
-template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false>
+//
+// KW = 2 (wide blocks on fp16 maps): two 16-channel K tiles per iteration -- the wide blocks run one or two workgroups per CU
+// through six short barrier-separated phases per K tile (3.2 k cycles, a third of it fixed latencies); 32 channels per
+// iteration halve the barriers and the waits.  A block whose channel count leaves a single K tile for the last iteration
+// reads zeros for the missing one (descriptor range checks on the map, the weights and the parameters).
+template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false, int KW = 1>
 // (a fourth workgroup per CU for the narrowest blocks -- 128 VGPRs, 32 KB of LDS -- measured slower: 146/265 vs 143/218 us at
 // C = 24, 256^2 / 320^2 maps; the memory system, not the CU, is what these blocks wait for)
 __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(const float *__restrict__ x,
@@ -106,6 +111,8 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                                                                                int tpb, int dbg_arg) {
     static_assert(F16 || !(HIN || HOUT), "fp16 maps go with fp16 1x1 operands");
     static_assert(!MM || F16, "the matrix-core depthwise takes fp16 operands");
+    static_assert(KW == 1 || (KW == 2 && MM && F16), "two K tiles per iteration: matrix-core depthwise only");
+    constexpr int NPT = kNP * KW, KTT = kKT * KW;  // channel pairs / channels per iteration
 #ifdef GFN_ABLATE  // timing experiments only (tools/ablate_convblock.py): skip parts of the kernel; results are wrong
     const int dbg = dbg_arg;
     // bit 64: s_memtime stamps at the phase boundaries of a few workgroups (device printf at the end)
@@ -125,14 +132,14 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     constexpr int RV4 = (TW + 8) / 4;       // float4 per staged halo row and channel: cells col0-4 .. col0+TW+3
     constexpr int RPP = (TW + 8) * 2 + 4;   // LDS floats per halo row of a channel pair (+4: bank spread)
     constexpr int PP = HR * RPP;            // LDS floats per channel pair
-    constexpr int PS = kNP * HR * RV4;      // staging slots: one = the same 4 cells of both channels of a pair
+    constexpr int PS = NPT * HR * RV4;      // staging slots: one = the same 4 cells of both channels of a pair
     constexpr int XPP = (PS + NT - 1) / NT;
     constexpr int BM = 32 * MT, BMS = BM * NS;
     constexpr int GP = F16 ? 2 : 4;         // 16-byte operand groups per weight row and K tile
-    constexpr int AV4 = GP * BMS;           // 16-byte pieces of one weight tile
+    constexpr int AV4 = KW * GP * BMS;      // 16-byte pieces of one iteration's weight tile(s)
     constexpr int APT = (AV4 + NT - 1) / NT;
     constexpr int PW = MM ? kMM2 : kCP2;    // parameter dwords per channel pair
-    constexpr int PPT = (kNP * PW + NT - 1) / NT;  // parameter dwords per thread and K tile
+    constexpr int PPT = (NPT * PW + NT - 1) / NT;  // parameter dwords per thread and iteration
     // MM: the halo in LDS is fp16, one dword = the two channels of a cell; PH dwords per halo row -- the pitch that puts the 16
     // lanes of a ds_read_b128 group (row segment r = m % RS, chunk c = m / RS, piece kg) on distinct banks
     constexpr int PH = TW == 8 ? 24 : 48;
@@ -147,13 +154,13 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     // ds_read_b128 group back on all 32 banks (measured: 69% of LDS cycles were bank conflicts without it).
     constexpr bool SWZ = NB == 2;
 
-    __shared__ __attribute__((aligned(16))) float Xs[MM ? kNP * HR * PH : kNP * PP];
+    __shared__ __attribute__((aligned(16))) float Xs[MM ? NPT * HR * PH : kNP * PP];
     // fp32: [buf][(sg*2+kh)*BMS + m] = A operands of k-steps 4sg .. 4sg+3;  fp16: [buf][kg*BMS + m] = 8 halfs k = 8kg ..
-    __shared__ float4 As4[2][GP * BMS];
+    __shared__ float4 As4[2][KW * GP * BMS];
     // B operand tile: fp32 [channel k][cell]; fp16 [pair][cell] of half2 (channels 2p, 2p+1) -- consecutive depthwise
     // threads write consecutive 16-byte pieces, the matrix lanes read consecutive dwords
-    __shared__ __attribute__((aligned(16))) float Bs[F16 ? kNP * BN : kKT * BN];
-    __shared__ __attribute__((aligned(16))) float Ps[kNP * PW];
+    __shared__ __attribute__((aligned(16))) float Bs[F16 ? NPT * BN : kKT * BN];
+    __shared__ __attribute__((aligned(16))) float Ps[NPT * PW];
     // The 1x1 bias of the item's output slabs, by item parity.  It rides the load pipeline (fetched with an item's first K tile,
     // filed at that tile's commit): fetched in the epilogue its wait would be vmcnt(0) -- on gfx9 that also waits for the next
     // item's prefetch and for the previous accumulator tile's stores to be acknowledged (measured: the store phase cost as
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     const unsigned lb = gfn::xcd_remap(blockIdx.x, gridDim.x);
     const unsigned w_begin = lb * (unsigned)tpb;
     const unsigned w_end = w_begin + (unsigned)tpb < nwork ? w_begin + (unsigned)tpb : nwork;
-    const int nk = Kp / kKT;
+    const int nk = (Kp / kKT + KW - 1) / KW;
     const int total = (int)(w_end - w_begin) * nk;
     auto decode = [&](unsigned item, int &b, int &row0, int &col0, int &m0) {
         const unsigned grp = item % (unsigned)ngrp;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         }
     };
     if (!(dbg & 32))
-        for (int e = tid; e < (MM ? kNP * HR * PH : kNP * PP) / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < (MM ? NPT * HR * PH : kNP * PP) / 4; e += NT) reinterpret_cast<float4 *>(Xs)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     static_assert(APT <= 4, "weight tile slots");
     static_assert(BMS <= NT, "one bias value per thread");
@@ -237,14 +244,14 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
     float bias_r = 0.f;
     const cb_rsrc_t a_rsrc = cb_rsrc(F16 ? packed + pd.wt16_off() : wt, (unsigned)Kp * (unsigned)Mp * (F16 ? 2u : 4u));
     const cb_rsrc_t p_rsrc = cb_rsrc(cp, (unsigned)(Kp / 2) * PW * 4u);
-    auto a_load = [&](int kt, int i) { return cb_ld4(a_rsrc, av[i] + (unsigned)(kt * GP * Mp) * 16u); };
+    auto a_load = [&](int kt, int i) { return cb_ld4(a_rsrc, av[i] + (unsigned)(kt * KW * GP * Mp) * 16u); };
     auto a_store = [&](int buf, int i, const float4 &v) {
         const int e = tid + NT * i;
         if (e < AV4) As4[buf][e] = v;
     };
     auto issue = [&]() {  // fetch (l_item, l_kt) into registers, advance the load stage
         if (dbg & 1) return;
-        const unsigned kx = (unsigned)l_kt * (unsigned)((HIN ? kNP : kKT) * plane) * 4u;  // the K tile's first pair / channel
+        const unsigned kx = (unsigned)l_kt * (unsigned)((HIN ? NPT : KTT) * plane) * 4u;  // the iteration's first pair / channel
 #pragma unroll
         for (int i = 0; i < XPP; ++i) {
             xr0[i] = cb_ld4(x_rsrc, (unsigned)xg[i] + kx);  // HIN: 4 cells of a channel pair; past C: zeros (their taps are 0 too)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 2) ar2 = a_load(l_kt, 2);
         if constexpr (APT > 3) ar3 = a_load(l_kt, 3);
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) pr[i] = cb_ld(p_rsrc, (unsigned)(l_kt * kNP * PW + min(tid + NT * i, kNP * PW - 1)) * 4u);
+        for (int i = 0; i < PPT; ++i) pr[i] = cb_ld(p_rsrc, (unsigned)(l_kt * NPT * PW + min(tid + NT * i, NPT * PW - 1)) * 4u);
         r_valid = l_valid | (l_kt == 0 && l_item != w_begin ? 256 : 0);
         if (l_kt == 0) {
             r_valid |= 512 | (((l_item - w_begin) & 1u) ? 1024 : 0);
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
         if constexpr (APT > 3) a_store(buf, 3, ar3);
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
-            if (PPT * NT == kNP * PW || tid + NT * i < kNP * PW) Ps[tid + NT * i] = pr[i];
+            if (PPT * NT == NPT * PW || tid + NT * i < NPT * PW) Ps[tid + NT * i] = pr[i];
         if ((r_valid & 512) && tid < BMS) Bias_s[(r_valid >> 10) & 1][tid] = bias_r;
     };
 
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
                     tix[i] = ch * 40 + ((unsigned)dx <= 4u ? dx : 5);
                 }
 #pragma unroll
-                for (int pi = 0; pi < kNP / (4 * NS); ++pi) {
+                for (int pi = 0; pi < NPT / (4 * NS); ++pi) {
                     const int pr_ = wave + 4 * NS * pi;  // channel pair of the K tile
                     const float *tw = &Ps[pr_ * kMM2];
                     f16x8 T[5];
@@ -460,16 +467,19 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
             if (dbg & 4) break;
             const int cell = (g * 4 + cw) * 32 + col;  // this lane's B column
             if constexpr (F16) {  // one v_mfma_f32_32x32x16_f16 per row tile: lane (n or m = lane&31, kg = lane>>5) holds 8 halfs
-                // channel pairs 4kh .. 4kh+3 of this cell = halfs k = 8kh .. 8kh+7
-                const float *bp = &Bs[4 * kh * BN + cell];
-                const f32x4 bq = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
-                const f16x8 bv = __builtin_bit_cast(f16x8, bq);
-                const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][kh * BMS + slab * BM + col]);
-                f16x8 av[MT];
+                // channel pairs 4kh .. 4kh+3 of this cell = halfs k = 8kh .. 8kh+7 (of k-step ks)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) av[i] = asrc[i * 32];
+                for (int ks = 0; ks < KW; ++ks) {
+                    const float *bp = &Bs[(8 * ks + 4 * kh) * BN + cell];
+                    const f32x4 bq = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
+                    const f16x8 bv = __builtin_bit_cast(f16x8, bq);
+                    const f16x8 *asrc = reinterpret_cast<const f16x8 *>(&As4[buf][(ks * GP + kh) * BMS + slab * BM + col]);
+                    f16x8 avv[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[g * MT + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv, acc[g * MT + i], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) avv[i] = asrc[i * 32];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[g * MT + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avv[i], bv, acc[g * MT + i], 0, 0, 0);
+                }
             } else {
                 // B operands of all 8 k-steps and the A operands of k-steps 0..3 are fetched up front; each row
                 // tile's A operands of k-steps 4..7 are fetched as soon as its first four MFMAs are issued
@@ -584,7 +594,7 @@ static int g_conv_tpb = [] {
     return e ? atoi(e) : 0;
 }();
 
-template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false>
+template <int MT, int TW, int NS, bool F16, int NB, bool HIN = false, bool HOUT = false, bool MM = false, int KW = 1>
 int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     constexpr int TH = kBN * NB / TW;
     const int tiles_x = (G + TW - 1) / TW, tiles_y = (G + TH - 1) / TH;
@@ -595,7 +605,7 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
     int tpb = nwork >= 16384 ? 2 : 1;  // measured: pays only on the largest grids
     if (g_conv_tpb > 0) tpb = g_conv_tpb;
     const unsigned grid = (unsigned)((nwork + tpb - 1) / tpb);
-    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB, HIN, HOUT, MM>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
+    hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB, HIN, HOUT, MM, KW>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,
                        tiles_y, ngrp, (unsigned)nwork, tpb, dbg);
     return gfn::check_launch("dwpw_fused_kernel");
 }
@@ -604,7 +614,7 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
 // (M <= 448: every refiner), so the depthwise arithmetic of a cell tile is done once.  Narrow blocks
 // (M <= 96: the fine scales, bound by LDS and HBM traffic rather than the matrix core) take 256-cell
 // tiles with two output rows per depthwise thread when the map divides into them.
-template <int TW, bool F16, bool HIN = false, bool HOUT = false, bool MM = false>
+template <int TW, bool F16, bool HIN = false, bool HOUT = false, bool MM = false, int KW = 1>
 int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     const int tiles = (M + 31) / 32;
     static const bool nb1 = getenv("GFN_CONV_NB1") != nullptr;  // experiments: 128-cell tiles for the narrow blocks too
@@ -623,19 +633,19 @@ int launch_fused(const float *x, const float *packed, float *y, int B, int M, in
             case 1: return launch_fused_mt<1, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
             case 2: return launch_fused_mt<2, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
             case 3: return launch_fused_mt<3, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-            case 4: return launch_fused_mt<4, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-            case 5: return launch_fused_mt<5, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-            case 6: return launch_fused_mt<6, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-            default: return launch_fused_mt<7, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+            case 4: return launch_fused_mt<4, TW, 1, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+            case 5: return launch_fused_mt<5, TW, 1, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+            case 6: return launch_fused_mt<6, TW, 1, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+            default: return launch_fused_mt<7, TW, 1, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
         }
     }
     const int ngrp = (tiles + 13) / 14;
     const int mt = ((tiles + ngrp - 1) / ngrp + 1) / 2;  // row tiles per slab
     switch (mt) {
-        case 4: return launch_fused_mt<4, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-        case 5: return launch_fused_mt<5, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-        case 6: return launch_fused_mt<6, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
-        default: return launch_fused_mt<7, TW, 2, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);
+        case 4: return launch_fused_mt<4, TW, 2, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+        case 5: return launch_fused_mt<5, TW, 2, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+        case 6: return launch_fused_mt<6, TW, 2, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
+        default: return launch_fused_mt<7, TW, 2, F16, 1, HIN, HOUT, MM, KW>(x, packed, y, B, M, K, G, dbg, s);
     }
 }
 

@@ -14,10 +14,20 @@ namespace {
 static const bool g_valu_dw = getenv("GFN_CONV_VALU_DW") != nullptr;
 static const int g_tw16_min = getenv("GFN_CONV_TW16_MIN") ? atoi(getenv("GFN_CONV_TW16_MIN")) : 0;
 
+// GFN_CONV_KW1: one K tile per iteration for the wide blocks too (experiments)
+static const bool g_kw1 = getenv("GFN_CONV_KW1") != nullptr;
+
 template <bool HIN, bool HOUT, bool MM>
 int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, int dbg, hipStream_t s) {
     const float *xf = (const float *)x;
     float *yf = (float *)y;
+    if constexpr (HIN && HOUT && MM) {  // blocks between two half maps, wide enough for more than three accumulator row tiles
+        if (M > 96 && !g_kw1) {
+            if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT, MM, 2>(xf, packed, yf, B, M, C, G, dbg, s);
+            if (G % 16 == 0 || G > (g_tw16_min ? g_tw16_min : 64)) return launch_fused<16, true, HIN, HOUT, MM, 2>(xf, packed, yf, B, M, C, G, dbg, s);
+            return launch_fused<8, true, HIN, HOUT, MM, 2>(xf, packed, yf, B, M, C, G, dbg, s);
+        }
+    }
     if (G % 32 == 0 || G > 160) return launch_fused<32, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
     if (G % 16 == 0 || G > (g_tw16_min ? g_tw16_min : 64)) return launch_fused<16, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
     return launch_fused<8, true, HIN, HOUT, MM>(xf, packed, yf, B, M, C, G, dbg, s);
