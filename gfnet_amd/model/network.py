@@ -15,8 +15,10 @@ code stays PyTorch-ROCm for the FPN/transformer backbone"): pass it in as `backb
 `backbone(images, upsample) -> (pyramid_A, pyramid_B)` with the dict layout of
 GFNet.extract_features (model/network.py:156-201), or feed pyramids directly to
 `forward_pyramids` / `match_pyramids`.  The refiner's depthwise/pointwise conv stack
-(model/network.py:560-563) runs on csrc/conv_stack.hip in eval mode; training mode keeps the nn modules and
-assembles the refiner input with differentiable torch ops (the HIP assembly has no backward).
+(model/network.py:560-563) runs on csrc/conv_stack.hip / conv_stack_half.hip in eval mode (`conv_precision`:
+"fp32" exact fp32 products, "fp16" fp16 1x1 operands, "amp" the class the reference's amp=True refiners run in under
+torch.autocast -- fp16 maps between the blocks); training mode keeps the nn modules and assembles the refiner input with
+differentiable torch ops (the HIP assembly has no backward).
 """
 import math
 
