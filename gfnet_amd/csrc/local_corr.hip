@@ -283,14 +283,15 @@ __global__ __launch_bounds__(256) void local_corr_bwd_f0_kernel(LcParams p, cons
 // per lane.  Issue and commit are separate so that a whole chunk's loads are in flight at once and
 // the NEXT chunk's loads stay in flight across the D-stage.  Addresses are clamped instead of
 // branched around (a conditional load becomes a branch + wait per element).
-template <int N>
+template <int N, typename FT>
 struct StageRegs {
-    float4 v[N];
+    FT v[N][4];  // as stored: fp16 values are widened at the commit (widening at the load makes hipcc wait for the loads in
+                 // small groups instead of keeping a chunk's worth in flight)
     int dst[N];  // float4 index in the stage, or -1
 };
 
 template <int N, typename FT>
-__device__ __forceinline__ void stage_issue(StageRegs<N> &r, const FT *f1c, int H, int W, const Region &rg, int wave,
+__device__ __forceinline__ void stage_issue(StageRegs<N, FT> &r, const FT *f1c, int H, int W, const Region &rg, int wave,
                                             int lane, int wi_begin) {
     const int npx = rg.w * rg.h;
     const int nwi = ((npx + 63) >> 6) * 4;
@@ -308,19 +309,19 @@ __device__ __forceinline__ void stage_issue(StageRegs<N> &r, const FT *f1c, int 
         // one VGPR per address instead of a 64-bit pair
         const unsigned off = ok ? (unsigned)(cg * 4) * pl32 + (unsigned)((rg.y0 + y) * W + (rg.x0 + x)) : 0u;
         const unsigned st = ok ? pl32 : 0u;
-        r.v[u].x = ldf(f1c + off);
-        r.v[u].y = ldf(f1c + (off + st));
-        r.v[u].z = ldf(f1c + (off + 2 * st));
-        r.v[u].w = ldf(f1c + (off + 3 * st));
+        r.v[u][0] = f1c[off];
+        r.v[u][1] = f1c[off + st];
+        r.v[u][2] = f1c[off + 2 * st];
+        r.v[u][3] = f1c[off + 3 * st];
         r.dst[u] = ok ? (y * rg.pitch + x) * kSlotV4 + cg : -1;
     }
 }
 
-template <int N>
-__device__ __forceinline__ void stage_commit(float4 *s4, const StageRegs<N> &r) {
+template <int N, typename FT>
+__device__ __forceinline__ void stage_commit(float4 *s4, const StageRegs<N, FT> &r) {
 #pragma unroll
     for (int u = 0; u < N; ++u)
-        if (r.dst[u] >= 0) s4[r.dst[u]] = r.v[u];
+        if (r.dst[u] >= 0) s4[r.dst[u]] = make_float4((float)r.v[u][0], (float)r.v[u][1], (float)r.v[u][2], (float)r.v[u][3]);
 }
 
 // whatever of the region the first `done` wave-iterations per wave did not cover
@@ -329,7 +330,7 @@ __device__ __forceinline__ void stage_rest(float4 *s4, const FT *f1c, int H, int
                                            int done) {
     const int nwi = ((rg.w * rg.h + 63) >> 6) * 4;
     for (int wi0 = done * kWaves; wi0 < nwi; wi0 += kWaves * N) {
-        StageRegs<N> r;
+        StageRegs<N, FT> r;
         stage_issue(r, f1c, H, W, rg, wave, lane, wi0);
         stage_commit(s4, r);
     }
@@ -505,10 +506,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     // round trip instead of in front of it
     const FT *f1b = f1_of<FT>(p, b);
     constexpr int PRE = 4;  // wave-iterations of stage loads kept in flight (48 x 64 px x 4 ch = a 768-pixel region)
-    StageRegs<PRE> pre;
+    StageRegs<PRE, FT> pre;
     constexpr int PRE0 = R <= 2 ? 4 : 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at
                                           // once (r <= 2 regions need 3.5 iterations; unused ones still cost their index math)
-    StageRegs<PRE0> pre0;
+    StageRegs<PRE0, FT> pre0;
     if (STAGED && !ABL(p, 1)) stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
 
     // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
@@ -621,7 +622,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                 constexpr int TG = 4;
 #pragma unroll
                 for (int t0 = 0; t0 < NP; t0 += TG) {
-                    float v[TG][kChunk];
+                    FT v[TG][kChunk];  // as stored: fp16 values are widened at their use (widening at the load made hipcc wait for
+                                       // the gathers in small groups: the scattered-flow path ran 2x slower on fp16 maps)
                     bool in[TG];
 #pragma unroll
                     for (int tt = 0; tt < TG; ++tt) {
@@ -632,7 +634,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                             in[tt] = (pp < P) & ((unsigned)X < (unsigned)W) & ((unsigned)Y < (unsigned)H) & !ABL(p, 2048);
                             const unsigned off = in[tt] ? (unsigned)(Y * W + X) : 0u;  // offset 0 when outside: valid memory, masked below
 #pragma unroll
-                            for (int k = 0; k < kChunk; ++k) v[tt][k] = ldf(f1c + k * plane + off);  // scalar plane base + 32-bit lane offset
+                            for (int k = 0; k < kChunk; ++k) v[tt][k] = f1c[k * plane + off];  // scalar plane base + 32-bit lane offset
                         }
                     }
 #pragma unroll
@@ -640,7 +642,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
                         if (t0 + tt < NP) {
                             float a = acc[rd][t0 + tt];
 #pragma unroll
-                            for (int k = 0; k < kChunk; ++k) a = fmaf(f[k], in[tt] ? v[tt][k] : 0.f, a);
+                            for (int k = 0; k < kChunk; ++k) a = fmaf(f[k], in[tt] ? (float)v[tt][k] : 0.f, a);
                             acc[rd][t0 + tt] = a;
                         }
                     }
