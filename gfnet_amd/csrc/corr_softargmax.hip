@@ -55,11 +55,90 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
     const float y_lo = (float)(-1 + 1.0 / H1), y_hi = (float)(1 - 1.0 / H1);
     const float inv_w1 = 1.0f / (float)W1;
     float m = -INFINITY, l = 0.f, ax = 0.f, ay = 0.f;
-    const bool row_tiles = W1 == 32;                       // wave-uniform
     const float e_scale = 1.4426950408889634f / sqrt_c;    // exp(v / sqrt(C)) = exp2(v * log2(e) / sqrt(C))
-    float gx16[16];
+
+    // ---- row tiles (flow only, 32 <= W1 <= 64: the 448 and 672 configurations) ---------------------------------------------
+    // A tile of 32 B-positions is (part of) ONE grid row: positions x = 32 p .. 32 p + 31 of row y, those past the row's end
+    // masked out (W1 = 48: the second tile of a row is half empty -- a third more matrix work).  Its y coordinate is then
+    // wave-uniform, the 16 x coordinates of a lane's accumulator rows are two constant sets, and the 1/sqrt(C) scale folds into
+    // the exponent: ~6 VALU instructions per value instead of ~40.  The kernel is VALU-bound (the fp32 MFMA shares the vector
+    // ALUs): 48x48 maps, which took the general path below, ran 6.5x longer than 32x32 ones for 2.5x the work.
+    if (WRITE_FLOW && !WRITE_VOL && W1 >= 32 && W1 <= 64) {  // wave-uniform
+        const int parts = W1 > 32 ? 2 : 1;
+        float gxA[16], gxB[16];
+        unsigned maskB = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gx16[r] = gfn::linspace_at(x_lo, x_hi, W1, min((r & 3) + 8 * (r >> 2) + 4 * h, W1 - 1));
+        for (int r = 0; r < 16; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+            gxA[r] = gfn::linspace_at(x_lo, x_hi, W1, min(o, W1 - 1));
+            gxB[r] = gfn::linspace_at(x_lo, x_hi, W1, min(32 + o, W1 - 1));
+            maskB |= (32 + o < W1 ? 1u : 0u) << r;
+        }
+        auto load_row_tile = [&](float (&a)[KS], int t) {
+            const int y = parts == 1 ? t : t >> 1, pp = parts == 1 ? 0 : t & 1;
+            const int jl = y * W1 + min(32 * pp + col, W1 - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[s] = (float)f1b[(size_t)min(2 * s + h, C - 1) * N1 + jl];  // channels >= C meet a zero in bop
+        };
+        auto softmax_tile = [&](f32x16 acc, const float (&gx)[16], int y) {
+            float mt = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
+            const float mn = fmaxf(m, mt);
+            const float sc = __builtin_amdgcn_exp2f((m - mn) * e_scale);  // m = -inf on the first tile -> 0
+            float lt = 0.f, axt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f((acc[r] - mn) * e_scale);  // masked positions: exp2(-inf) = 0
+                lt += e;
+                axt = fmaf(e, gx[r], axt);
+            }
+            const float gy = gfn::linspace_at(y_lo, y_hi, H1, y);
+            l = fmaf(l, sc, lt);
+            ax = fmaf(ax, sc, axt);
+            ay = fmaf(ay, sc, lt * gy);
+            m = mn;
+        };
+        const int ntiles = H1 * parts;
+        float a_cur[KS], a_nxt[KS];
+        load_row_tile(a_cur, 0);
+        // land the first tile before the loop: otherwise the wait-count pass assumes 64 loads in flight at the loop head and
+        // makes every MFMA of every tile wait for the *prefetch* it was meant to overlap with
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(a_cur[s]));
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) load_row_tile(a_nxt, t + 1);
+            // two independent accumulation chains (even / odd k-steps): a single chain left the matrix pipe waiting on its own
+            // result between issues (0.152 -> 0.122 ms for 64 directions; four chains: 0.131); summed at the end
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bop[s], acc, 0, 0, 0);
+                if (s + 1 < KS) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s + 1], bop[s + 1], acc2, 0, 0, 0);
+            }
+            acc += acc2;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
+            if (parts == 1 || !(t & 1)) {
+                softmax_tile(acc, gxA, parts == 1 ? t : t >> 1);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = ((maskB >> r) & 1u) ? acc[r] : -INFINITY;
+                softmax_tile(acc, gxB, t >> 1);
+            }
+        }
+        m = m / sqrt_c;  // the running maximum was kept in unscaled units
+        const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
+        const float mn = fmaxf(m, m2);
+        const float s1 = __expf(m - mn), s2 = __expf(m2 - mn);
+        const float lt = l * s1 + l2 * s2;
+        const float fx = (ax * s1 + ax2 * s2) / lt, fy = (ay * s1 + ay2 * s2) / lt;
+        if (h == 0 && i < N0) {
+            flow[((size_t)b * 2 + 0) * N0 + i] = fx;
+            flow[((size_t)b * 2 + 1) * N0 + i] = fy;
+        }
+        return;
+    }
 
     // A operand of one tile (32 B-positions x all channels): loads are branch-free (clamped address) so the
     // compiler batches them, and the next tile's operand is requested before this tile's MFMA chain starts -- with two
@@ -90,29 +169,6 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
         acc += acc2;
 #pragma unroll
         for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
-        if (WRITE_FLOW && !WRITE_VOL && row_tiles) {
-            // W1 == 32: a tile of 32 B-positions is one grid row -- its y coordinate is wave-uniform, the 16 x coordinates of
-            // this lane's accumulator rows never change, and the 1/sqrt(C) scale folds into the exponent.  ~6 VALU
-            // instructions per value instead of ~40: the kernel was VALU-bound (the fp32 MFMA shares the vector ALUs).
-            float mt = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
-            const float mn = fmaxf(m, mt);
-            const float sc = __builtin_amdgcn_exp2f((m - mn) * e_scale);  // m = -inf on the first tile -> 0
-            float lt = 0.f, axt = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f((acc[r] - mn) * e_scale);
-                lt += e;
-                axt = fmaf(e, gx16[r], axt);
-            }
-            const float gy = gfn::linspace_at(y_lo, y_hi, H1, j0 >> 5);
-            l = fmaf(l, sc, lt);
-            ax = fmaf(ax, sc, axt);
-            ay = fmaf(ay, sc, lt * gy);
-            m = mn;
-            continue;
-        }
         float sv[16];
         float mt = -INFINITY;
 #pragma unroll
@@ -142,7 +198,6 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
             m = mn;
         }
     }
-    if (WRITE_FLOW && !WRITE_VOL && row_tiles) m = m / sqrt_c;  // the running maximum was kept in unscaled units
     if (WRITE_FLOW) {
         // merge the two half-waves (same column i, disjoint rows j)
         const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
