@@ -139,8 +139,18 @@ class StandInRefiner(nn.Module):
         self.targets = targets  # {num_grid: ([k * (true flow + noise_itr) for itr], k)}
         self._cert, self._calls = {}, {}
 
-    def forward(self, num_grid, x, y, flow, scale_factor=1):
-        d, lc = self.inner.assemble(num_grid, x, y, flow, scale_factor)
+    supports_reuse_d = True  # GFNet.forward_pyramids: later iterations at a scale keep the grid_feature planes
+
+    @property
+    def last_d(self):
+        return self.inner.last_d
+
+    @last_d.setter
+    def last_d(self, v):
+        self.inner.last_d = v
+
+    def forward(self, num_grid, x, y, flow, scale_factor=1, reuse_d=None):
+        d, lc = self.inner.assemble(num_grid, x, y, flow, scale_factor, reuse=reuse_d)
         tk, k = self.targets[num_grid]
         itr = self._calls.get(num_grid, 0)
         self._calls[num_grid] = (itr + 1) % self.num_itr

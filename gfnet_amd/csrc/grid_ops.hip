@@ -18,9 +18,9 @@ namespace {
 
 using namespace gfn_ri;
 
-template <typename FT>
+template <typename FT, bool KEEP>
 __global__ __launch_bounds__(256) void refiner_input_kernel(RiArgs q) {
-    refiner_input_cell<FT>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * 256u + threadIdx.x);
+    refiner_input_cell<FT, KEEP>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * 256u + threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
@@ -245,16 +245,22 @@ GFN_EXPORT int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtyp
     if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b)))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: null pointer");
     if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G ||
-        (symmetric && (B & 1)) || (long)C * Hs * Ws >= (1L << 31))
+        ((symmetric & 1) && (B & 1)) || (symmetric & ~3) || (long)C * Hs * Ws >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
     if (B == 0) return GFN_OK;
     if (B > 65535 || (long)G * G >= (1L << 31)) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: batch > 65535 or grid too large");
     const dim3 grid((unsigned)(((long)G * G + 255) / 256), (unsigned)B);
     RiArgs q;
     q.fa = f0; q.fb = f1; q.flow = flow; q.dw = disp_w; q.db = disp_b; q.d = d; q.d_bs = (long)d_bs;
-    q.B = B; q.Bh = symmetric ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
-    if (dtype == GFN_F16) hipLaunchKernelGGL(refiner_input_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(refiner_input_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, q);
+    q.B = B; q.Bh = (symmetric & 1) ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
+    const bool keep = (symmetric & 2) != 0;  // the grid_feature planes are already in d (GFN_RI_KEEP_GRID_FEATURE)
+    if (dtype == GFN_F16) {
+        if (keep) hipLaunchKernelGGL((refiner_input_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((refiner_input_kernel<_Float16, false>), grid, dim3(256), 0, (hipStream_t)stream, q);
+    } else {
+        if (keep) hipLaunchKernelGGL((refiner_input_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((refiner_input_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, q);
+    }
     return gfn::check_launch("refiner_input_kernel");
 }
 

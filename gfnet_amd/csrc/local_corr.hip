@@ -1040,12 +1040,13 @@ GFN_EXPORT int gfn_local_corr_plans(int C, int H, int W, int G, int r, int f1_dt
 
 namespace {
 template <int R, typename FT>
-int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s) {
+int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s, bool keep) {
     lean_window_params<R>(p);
     const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
-    hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
     return gfn::check_launch("refiner_input_plan_kernel");
 }
 }  // namespace
@@ -1056,8 +1057,8 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
                                              gfn_stream_t stream) {
     if (dtype != GFN_F32 && dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: feature dtype must be GFN_F32 or GFN_F16");
     if (!f0 || !f1 || !flow || !d || (disp_dim > 0 && (!disp_w || !disp_b))) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: null pointer");
-    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G || (symmetric && (B & 1)) ||
-        (long)C * Hs * Ws >= (1L << 31) || B > 65535 || (long)G * G >= (1L << 31))
+    if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G || ((symmetric & 1) && (B & 1)) ||
+        (symmetric & ~3) || (long)C * Hs * Ws >= (1L << 31) || B > 65535 || (long)G * G >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: bad size");
     if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: the local correlation of this shape takes no plan (ask gfn_local_corr_plans first)");
@@ -1066,7 +1067,8 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     if (B == 0) return GFN_OK;
     gfn_ri::RiArgs q;
     q.fa = f0; q.fb = f1; q.flow = flow; q.dw = disp_w; q.db = disp_b; q.d = d; q.d_bs = (long)d_bs;
-    q.B = B; q.Bh = symmetric ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
+    q.B = B; q.Bh = (symmetric & 1) ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
+    const bool keep = (symmetric & 2) != 0;  // the grid_feature planes are already in d
     LcParams p{};
     p.flow = flow; p.f16 = dtype == GFN_F16;
     p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
@@ -1075,10 +1077,10 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == GFN_F16;
     switch (r) {
-        case 1: return h ? launch_ri_plan<1, _Float16>(q, p, s) : launch_ri_plan<1, float>(q, p, s);
-        case 2: return h ? launch_ri_plan<2, _Float16>(q, p, s) : launch_ri_plan<2, float>(q, p, s);
-        case 3: return h ? launch_ri_plan<3, _Float16>(q, p, s) : launch_ri_plan<3, float>(q, p, s);
-        default: return h ? launch_ri_plan<4, _Float16>(q, p, s) : launch_ri_plan<4, float>(q, p, s);
+        case 1: return h ? launch_ri_plan<1, _Float16>(q, p, s, keep) : launch_ri_plan<1, float>(q, p, s, keep);
+        case 2: return h ? launch_ri_plan<2, _Float16>(q, p, s, keep) : launch_ri_plan<2, float>(q, p, s, keep);
+        case 3: return h ? launch_ri_plan<3, _Float16>(q, p, s, keep) : launch_ri_plan<3, float>(q, p, s, keep);
+        default: return h ? launch_ri_plan<4, _Float16>(q, p, s, keep) : launch_ri_plan<4, float>(q, p, s, keep);
     }
 }
 

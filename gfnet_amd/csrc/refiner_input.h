@@ -129,7 +129,10 @@ struct RiArgs {
     float disp_scale;
 };
 
-template <typename FT>
+// KEEP: the grid_feature planes (first C channels of d: grid_sample(x, cell centres), a function of x and the grid only) are
+// already in d from an earlier call with the same x and G -- the second refiner iteration at a scale (num_itr = 2,
+// model/network.py:257-268, calls the refiner again with a new flow): only x_hat and the displacement embedding are rewritten.
+template <typename FT, bool KEEP = false>
 __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, unsigned cell) {
     const FT *__restrict__ fa = static_cast<const FT *>(args.fa);
     const FT *__restrict__ fb = static_cast<const FT *>(args.fb);
@@ -158,7 +161,7 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
                 const FT *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    va[k][e] = ld_pair(qp + sa.o[e]);
+                    if (!KEEP) va[k][e] = ld_pair(qp + sa.o[e]);
                     vb[k][e] = ld_pair(sp + sb.o[e]);
                 }
             }
@@ -168,12 +171,14 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
                     float ra = 0.f, rb = 0.f;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        ra += va[k][e].x * sa.w[2 * e];
-                        ra += va[k][e].y * sa.w[2 * e + 1];
+                        if (!KEEP) {
+                            ra += va[k][e].x * sa.w[2 * e];
+                            ra += va[k][e].y * sa.w[2 * e + 1];
+                        }
                         rb += vb[k][e].x * sb.w[2 * e];
                         rb += vb[k][e].y * sb.w[2 * e + 1];
                     }
-                    (o + (size_t)(c0 + k) * GG)[cell] = ra;  // read back at once as the local correlation's f0: stays cached
+                    if (!KEEP) (o + (size_t)(c0 + k) * GG)[cell] = ra;  // read back at once as the local correlation's f0: stays cached
                     __builtin_nontemporal_store(rb, o + (size_t)(C + c0 + k) * GG + cell);
                 }
             }
@@ -185,10 +190,10 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
             float ra = 0.f, rb = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                ra += (float)(q + (size_t)c * plane)[sa.o[e]] * sa.w[e];
+                if (!KEEP) ra += (float)(q + (size_t)c * plane)[sa.o[e]] * sa.w[e];
                 rb += (float)(sm + (size_t)c * plane)[sb.o[e]] * sb.w[e];
             }
-            (o + (size_t)c * GG)[cell] = ra;
+            if (!KEEP) (o + (size_t)c * GG)[cell] = ra;
             (o + (size_t)(C + c) * GG)[cell] = rb;
         }
     }

@@ -83,17 +83,23 @@ class ConvRefiner(nn.Module):
         self.conv_precision = "fp32"
         self.fold_out_conv = True  # multiply out_conv into the last block's 1x1 conv (see folded_stack)
 
-    def assemble(self, num_grid, x, y, flow, scale_factor=1):
-        """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view."""
+    supports_reuse_d = True  # forward(..., reuse_d=): see GFNet.forward_pyramids
+    last_d = None
+
+    def assemble(self, num_grid, x, y, flow, scale_factor=1, reuse=None):
+        """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view.
+        reuse: the d of the previous iteration at this scale (same x, same grid): its grid_feature planes are kept."""
         if not self.has_displacement_emb:
             raise NotImplementedError("refiners without displacement embedding are not used by GFNet")
         c = x.shape[1]
         dd = self.disp_emb.weight.shape[0]
         use_corr = bool(self.corr_in_other)
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or self.disp_emb.weight.requires_grad):
+            self.last_d = None
             return self._assemble_autograd(num_grid, x, y, flow, scale_factor)
         d = ops.refiner_input(num_grid, x, y, flow, self.disp_emb.weight, self.disp_emb.bias,
-                              self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr)
+                              self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr, reuse=reuse)
+        self.last_d = d  # GFNet.forward_pyramids hands it back for the next iteration at the same scale
         return d, (d[:, 2 * c + dd:] if use_corr else None)
 
     def _assemble_autograd(self, num_grid, x, y, flow, scale_factor):
@@ -192,8 +198,10 @@ class ConvRefiner(nn.Module):
             C = M
         return x if out_conv is None else ops.pointwise_conv(x, out_conv[0], out_conv[1])
 
-    def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None):
-        d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor)
+    def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None, reuse_d=None):
+        """reuse_d (not in the reference): the concat tensor of the previous call when x and num_grid are unchanged -- the
+        second iteration at a scale (network.py:257-268); saves regathering grid_feature.  Results are identical."""
+        d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor, reuse=reuse_d)
         if self._hip_stack_supported():
             out = self.conv_stack(d)
         else:
@@ -290,7 +298,18 @@ class GFNet(nn.Module):
             corresps[scale] = {}
             disp_prev = torch.empty_like(flow) if num_itr[idx] > 1 else None  # carried between the iterations of one scale
             for itr in range(num_itr[idx]):
-                d_flow, d_cert, _ = self.conv_refiner[scale](num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
+                ref = self.conv_refiner[scale]
+                # later iterations at a scale see the same features and grid: the refiner keeps the grid_feature planes of
+                # its previous concat tensor (ConvRefiner.forward, reuse_d) instead of regathering them
+                prev_d = getattr(ref, "last_d", None) if (itr > 0 and getattr(ref, "supports_reuse_d", False)) else None
+                if prev_d is not None:
+                    d_flow, d_cert, _ = ref(num_grid[idx], f0, f1, flow, scale_factor=scale_factor, reuse_d=prev_d)
+                else:
+                    if hasattr(ref, "last_d"):
+                        ref.last_d = None
+                    d_flow, d_cert, _ = ref(num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
+                if itr + 1 == num_itr[idx] and hasattr(ref, "last_d"):
+                    ref.last_d = None  # do not keep the scale's concat tensor alive
                 # each iteration's result is kept (corresps): out-of-place update straight from the refiner's outputs
                 flow, certainty = ops.flow_update(flow, certainty, d_flow, d_cert, disp_prev, int(scale), W0, H0,
                                                   zero_small=not self.training, first_iteration=(itr == 0))  # :262-268

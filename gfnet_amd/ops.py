@@ -80,11 +80,13 @@ def pos_embed(corr_vol):
     return flow
 
 
-def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_factor=1.0, corr_in_other=True):
+def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_factor=1.0, corr_in_other=True, reuse=None):
     """The concat tensor `d` of ConvRefiner.forward (model/network.py:533-558):
     cat(grid_sample(x, cell centres), grid_sample(y, flow), disp_emb(40/32*scale_factor*(flow-centres)),
     local_correlation(...)) -- every slice written in place by the HIP kernels, no torch.cat.
-    If flow has twice the batch of x/y the call is symmetric: directions (x vs y) then (y vs x)."""
+    If flow has twice the batch of x/y the call is symmetric: directions (x vs y) then (y vs x).
+    reuse: the `d` an earlier call returned for the SAME x and num_grid (the previous refiner iteration at this scale): it is
+    overwritten in place except for its grid_feature planes, which depend on x and the grid only."""
     dev = require_gpu(x, y, flow, disp_w, disp_b)
     (x, dtx), (y, dty), fl = featc(x), featc(y), f32c(flow)
     if dtx != dty:
@@ -101,8 +103,15 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     r = int(local_radius)
     K = (2 * r + 1) ** 2 if corr_in_other else 0
     CH = 2 * C + Dd + K
-    d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
+    keep = reuse is not None
+    if keep:
+        if tuple(reuse.shape) != (B, CH, G, G) or reuse.dtype != torch.float32 or not reuse.is_contiguous() or reuse.device != dev:
+            raise ValueError("refiner_input: `reuse` must be the tensor an earlier call with the same shapes returned")
+        d = reuse
+    else:
+        d = torch.empty((B, CH, G, G), device=dev, dtype=torch.float32)
     st = stream_ptr(dev)
+    mode = (1 if symmetric else 0) | (2 if keep else 0)  # include/gfnet_hip.h: GFN_RI_KEEP_GRID_FEATURE
     disp_scale = float(40 / 32 * scale_factor)
     # shapes the lean local-correlation path takes are planned inside the refiner-input launch (both only read the flow)
     plans = corr_in_other and bool(_L().gfn_local_corr_plans(C, Hs, Ws, G, r, dtx))
@@ -111,10 +120,10 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
         scr = _lib.scratch(dev, nscr)
     if plans:
         check(_L().gfn_refiner_input_plan_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
-                                                 disp_scale, 1 if symmetric else 0, r, ptr(scr), nscr, st), "gfn_refiner_input_plan_fwd")
+                                                 disp_scale, mode, r, ptr(scr), nscr, st), "gfn_refiner_input_plan_fwd")
     else:
         check(_L().gfn_refiner_input_fwd_dt(ptr(x), ptr(y), dtx, ptr(fl), ptr(w), ptr(bvec), ptr(d), CH * G * G, B, C, Hs, Ws, G, Dd,
-                                            disp_scale, 1 if symmetric else 0, st), "gfn_refiner_input_fwd")
+                                            disp_scale, mode, st), "gfn_refiner_input_fwd")
     if corr_in_other:
         out = d[:, 2 * C + Dd:]
         name = f"local_corr_c{C}_h{Hs}_g{G}_r{r}"

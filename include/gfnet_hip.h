@@ -139,9 +139,13 @@ int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int 
  *                        disp_scale = 40/32 * scale_factor, disp_w (disp_dim,2), disp_b (disp_dim)
  * The local-correlation slice d[:, 2C+disp:] is filled by gfn_local_corr_fwd with
  * f0 = d (batch stride d_bs) and out = d + (2C+disp)*G*G (batch stride d_bs).
- * symmetric != 0: f0/f1 hold B/2 images each; direction b < B/2 queries f0[b] against f1[b],
+ * symmetric bit 0 (1): f0/f1 hold B/2 images each; direction b < B/2 queries f0[b] against f1[b],
  * direction b >= B/2 queries f1[b-B/2] against f0[b-B/2].
+ * symmetric bit 1 (2, GFN_RI_KEEP_GRID_FEATURE): d[:, 0:C] is left as it is -- grid_sample(f0, cell centres) depends on f0
+ * and G only, so the second refiner iteration at a scale (num_itr = 2, model/network.py:257-268: same features, new flow)
+ * passes the d of the first one and has only x_hat and the displacement embedding rewritten.
  */
+#define GFN_RI_KEEP_GRID_FEATURE 2
 int gfn_refiner_input_fwd(const float *f0, const float *f1, const float *flow, const float *disp_w, const float *disp_b,
                           float *d, int64_t d_bs, int B, int C, int Hs, int Ws, int G, int disp_dim, float disp_scale,
                           int symmetric, gfn_stream_t stream);

@@ -514,3 +514,27 @@ def test_sample_without_replacement_follows_the_weights():
     ref = torch.multinomial(dev(W), 3, replacement=False)
     incl_ref = np.bincount(host(ref).ravel(), minlength=8) / rows
     np.testing.assert_allclose(incl, incl_ref, atol=0.015)
+
+
+@pytest.mark.parametrize("c,hs,G,r,dtype", [(16, 56, 32, 2, torch.float32), (32, 28, 16, 4, torch.float16), (64, 16, 16, 7, torch.float32),
+                                            (8, 64, 32, 0, torch.float32)])
+def test_refiner_input_reuse_keeps_grid_feature(c, hs, G, r, dtype):
+    """Second refiner iteration at a scale (network.py:257-268: same features, new flow): `reuse=` hands the previous concat
+    tensor back, the kernels rewrite x_hat, the displacement embedding and the local correlation and leave the grid_feature
+    planes (a function of x and the grid only) alone -- bit-identical to a fresh call, for the planned (lean) and the other
+    local-correlation paths, fp32 and fp16 maps, symmetric batches."""
+    from gfnet_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, c, hs, hs, generator=g).cuda().to(dtype)
+    y = torch.randn(2, c, hs, hs, generator=g).cuda().to(dtype)
+    w, b = torch.randn(6, 2, generator=g).cuda(), torch.randn(6, generator=g).cuda()
+    flow1 = (torch.rand(4, 2, G, G, generator=g) * 1.6 - 0.8).cuda()
+    flow2 = (flow1 + 0.05 * torch.randn(4, 2, G, G, generator=g).cuda()).clamp(-0.95, 0.95)
+    d1 = ops.refiner_input(G, x, y, flow1, w, b, r, scale_factor=1.25, corr_in_other=r > 0)
+    want = ops.refiner_input(G, x, y, flow2, w, b, r, scale_factor=1.25, corr_in_other=r > 0)
+    got = ops.refiner_input(G, x, y, flow2, w, b, r, scale_factor=1.25, corr_in_other=r > 0, reuse=d1)
+    assert got.data_ptr() == d1.data_ptr()
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.refiner_input(G, x, y, flow2, w, b, r, scale_factor=1.25, corr_in_other=r > 0, reuse=d1[:, :-1].contiguous())
