@@ -825,6 +825,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 }
 
 #include "local_corr_lean.h"
+#include "local_corr_mm.h"
 
 // shapes the lean tile path takes (it keeps at most 8 channels of the f0 block per wave in registers, addresses planes with
 // 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
@@ -854,7 +855,15 @@ void lean_window_params(LcParams &p) {
 }
 
 template <int R, int NCH, typename FT>
-void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, bool mm) {
+    if constexpr (Lean<R>::kMM) {
+        if (mm) {  // D-stage on the matrix core (local_corr_mm.h)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_mm_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kMaxLds);
+            hipLaunchKernelGGL((local_corr_tile_mm_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
+            return;
+        }
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
@@ -873,7 +882,7 @@ int device_cu_count() {
 }
 
 template <int R, int ROUNDS, typename FT>
-int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
+int launch_tile(const LcParams &p0, hipStream_t stream, bool lean, bool mm) {
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
@@ -906,9 +915,9 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
                 if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
             }
             switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
-                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
-                default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
+                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream, mm); break;
+                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream, mm); break;
+                default: launch_lean<R, 4, FT>(p, total, lds2, stream, mm); break;
             }
             if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
             if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
@@ -980,10 +989,13 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
 #endif
 
     // the tiled path needs the tile list in scratch; without it the general kernel still gives the right answer
-    // variant 0: the tiled path (lean tile kernel for r <= 4); 1: general kernel; 2: the round-1 tile kernel for every radius
-    // (kept as the bit-exact cross-check of the lean kernel)
+    // variant 0: the tiled path (lean tile kernel for r <= 4, its D-stage on the matrix core where Lean<R>::kMM); 1: general
+    // kernel; 2: the round-1 tile kernel for every radius; 4: the lean tile kernel with the round-2 fp32 FMA D-stage (bit-identical
+    // to variant 2; kept as the cross-check of the matrix-core kernel)
     const bool planned = (variant & 8) != 0;  // gfn_refiner_input_plan_fwd_dt has already written this call's plan
     variant &= ~8;
+    const bool mm = variant == 0;
+    if (variant == 4) variant = 0;
     bool lean = variant == 0 && flow && !grid_based && win_h == H && win_w == W && lean_shape(C, H, W, G, r, p.f16);
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
     p.planned = planned ? 1 : 0;
@@ -997,23 +1009,23 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
         int rc = -1000;
         if (p.f16) {
             switch (r) {
-                case 1: rc = launch_tile<1, 2, _Float16>(p, s, lean); break;
-                case 2: rc = launch_tile<2, 2, _Float16>(p, s, lean); break;
-                case 3: rc = launch_tile<3, 2, _Float16>(p, s, lean); break;
-                case 4: rc = launch_tile<4, 2, _Float16>(p, s, lean); break;
-                case 5: rc = launch_tile<5, 1, _Float16>(p, s, lean); break;
-                case 6: rc = launch_tile<6, 1, _Float16>(p, s, lean); break;
-                case 7: rc = launch_tile<7, 1, _Float16>(p, s, lean); break;
+                case 1: rc = launch_tile<1, 2, _Float16>(p, s, lean, mm); break;
+                case 2: rc = launch_tile<2, 2, _Float16>(p, s, lean, mm); break;
+                case 3: rc = launch_tile<3, 2, _Float16>(p, s, lean, mm); break;
+                case 4: rc = launch_tile<4, 2, _Float16>(p, s, lean, mm); break;
+                case 5: rc = launch_tile<5, 1, _Float16>(p, s, lean, mm); break;
+                case 6: rc = launch_tile<6, 1, _Float16>(p, s, lean, mm); break;
+                case 7: rc = launch_tile<7, 1, _Float16>(p, s, lean, mm); break;
             }
         } else {
             switch (r) {
-                case 1: rc = launch_tile<1, 2, float>(p, s, lean); break;
-                case 2: rc = launch_tile<2, 2, float>(p, s, lean); break;
-                case 3: rc = launch_tile<3, 2, float>(p, s, lean); break;
-                case 4: rc = launch_tile<4, 2, float>(p, s, lean); break;
-                case 5: rc = launch_tile<5, 1, float>(p, s, lean); break;
-                case 6: rc = launch_tile<6, 1, float>(p, s, lean); break;
-                case 7: rc = launch_tile<7, 1, float>(p, s, lean); break;
+                case 1: rc = launch_tile<1, 2, float>(p, s, lean, mm); break;
+                case 2: rc = launch_tile<2, 2, float>(p, s, lean, mm); break;
+                case 3: rc = launch_tile<3, 2, float>(p, s, lean, mm); break;
+                case 4: rc = launch_tile<4, 2, float>(p, s, lean, mm); break;
+                case 5: rc = launch_tile<5, 1, float>(p, s, lean, mm); break;
+                case 6: rc = launch_tile<6, 1, float>(p, s, lean, mm); break;
+                case 7: rc = launch_tile<7, 1, float>(p, s, lean, mm); break;
             }
         }
         if (rc != -1000) return rc;  // -1000: shape not supported by the tiled path

@@ -44,6 +44,10 @@ struct Lean {
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
+    // matrix-core D-stage (local_corr_mm.h): a group of 2 x 8 cells is served by two waves, one per 16-position column tile of
+    // the group's window box, each holding at most NBW rows of 16 x 16 accumulator blocks
+    static constexpr bool kMM = false;  // round 3, first cut (2 workgroups x 8 waves, 16-channel chunks): 64 accumulators per wave spill; see local_corr_mm.h
+    static constexpr int NBW = 16;
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
@@ -102,6 +106,15 @@ __device__ __forceinline__ bool region_fits(RowPlan &u) {
     return true;
 }
 
+// min over each row of 16 lanes (a 2 x 8-cell group), valid in lane 15 of the row
+__device__ __forceinline__ int row_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    return v;
+}
+
 // ---- plan launch: a wave plans kPlanPerWave tiles (all their flow loads in flight together) -----------------------------
 constexpr int kPlanPerWave = 4;
 // one wave: the plans of tiles wid0 .. wid0 + kPlanPerWave - 1 (those below `total`)
@@ -129,16 +142,25 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
         const unsigned wid = wid0 + t;
         if (wid >= total) break;
         const CellBox c = cell_box<PW>(ok[t], nx[t], ny[t], -p.win_xhi, -p.win_yhi, p.W, p.H);
-        // boxes of the two halves (lanes 0-31 / 32-63), the tile's box is their union
-        const bool left = lane < 32;
+        // boxes of the four 2 x 8-cell groups (lanes 16 g .. 16 g + 15: one DPP row each), of the two halves (groups 0-1 / 2-3), and
+        // of the tile (their union)
+        const int rx0 = row_min_i32(c.bx0), ry0 = row_min_i32(c.by0), rx1 = row_min_i32(-c.bx1), ry1 = row_min_i32(-c.by1);
         int hx0[2], hy0[2], hx1[2], hy1[2];
+        bool mm_ok = true;  // every group's box fits two 16-position column tiles x NBW rows (the matrix-core D-stage's accumulators)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const bool mine = left == (h == 0);
-            hx0[h] = wave_min_i32(mine ? c.bx0 : kFar);
-            hy0[h] = wave_min_i32(mine ? c.by0 : kFar);
-            hx1[h] = -wave_min_i32(mine ? -c.bx1 : kFar);
-            hy1[h] = -wave_min_i32(mine ? -c.by1 : kFar);
+            int gx0[2], gy0[2], gx1[2], gy1[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int l15 = (2 * h + k) * 16 + 15;
+                gx0[k] = __builtin_amdgcn_readlane(rx0, l15);
+                gy0[k] = __builtin_amdgcn_readlane(ry0, l15);
+                gx1[k] = -__builtin_amdgcn_readlane(rx1, l15);
+                gy1[k] = -__builtin_amdgcn_readlane(ry1, l15);
+                if (Lean<R>::kMM && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= Lean<R>::NBW);
+            }
+            hx0[h] = min(gx0[0], gx0[1]); hy0[h] = min(gy0[0], gy0[1]);
+            hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
         }
         const bool all_in = __all(c.inside);
         if (lane == 0) {
@@ -162,7 +184,7 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 return region_fits<R>(u);
             };
             RowPlan ua, ub;
-            const bool border_ok = true;
+            const bool border_ok = mm_ok;
             int flags = all_in ? kPlanInterior : 0;
             const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
             ub = ua;
@@ -261,15 +283,16 @@ struct QuadRegs {
 constexpr int kQuadPre = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
 struct QuadItem {
     unsigned voff;        // byte offset of the lane's quad: (row * W + x) elements + the channel quad's four planes
-    unsigned meta;        // bits 0-11: float4 index of the lane's first pixel slot (+ cg); 12-15: pixels of the quad inside the
-                          // image (CHECK); 16: the lane has a quad in this item; 17: its row lies inside the image (CHECK)
+    unsigned meta;        // bits 0-12: index of the lane's first pixel slot (+ cg) in units of 80 / UNIT bytes (UNIT 5: float4s, the
+                          // fp32 stage; UNIT 10: 8-byte pieces, the bf16 hi/lo stage of local_corr_mm.h); 13-16: pixels of the quad
+                          // inside the image (CHECK); 17: the lane has a quad in this item; 18: its row lies inside the image (CHECK)
 };
 struct QuadLane {         // per lane and region, the first kQuadPre items of this wave
     QuadItem it[kQuadPre];
 };
 
 // item k of wave `wave`: where the lane's quad comes from and where it goes
-template <bool CHECK, typename FT>
+template <bool CHECK, typename FT, int UNIT = kSlotV4>
 __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, int wave, int lane, int k) {
     constexpr unsigned ES = sizeof(FT);
     const int cg = (lane >> 2) & 3;
@@ -290,11 +313,11 @@ __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, in
     // and rows outside it point at a pixel inside and are zeroed at the commit, like the pixels that hang over the right edge
     const int px = CHECK ? (row_in ? gy : 0) * W + max(x, 0) : row * W + x;  // !CHECK: relative to the region's first row
     o.voff = (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES;
-    o.meta = (unsigned)((row * u.pitch + 4 * q) * kSlotV4 + cg) | (xmask << 12) | (have ? 1u << 16 : 0u) | (row_in ? 1u << 17 : 0u);
+    o.meta = (unsigned)((row * u.pitch + 4 * q) * UNIT + cg) | (xmask << 13) | (have ? 1u << 17 : 0u) | (row_in ? 1u << 18 : 0u);
     return o;
 }
 
-template <int N, bool CHECK, typename FT>
+template <int N, bool CHECK, typename FT, int UNIT = kSlotV4>
 __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
                                            int lane, const QuadLane &ql, int k0) {
     constexpr unsigned ES = sizeof(FT);
@@ -307,7 +330,7 @@ __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsig
         // no branch around the loads: an item past the wave's last one repeats the last one (L1 hits, result unused)
         unsigned vo;
         if (k0 == 0 && n < kQuadPre) vo = (n == 0 || n < ipw) ? ql.it[n].voff : ql.it[0].voff;
-        else vo = quad_item<CHECK, FT>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
+        else vo = quad_item<CHECK, FT, UNIT>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
     }
@@ -320,10 +343,10 @@ __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const unsigned meta = (k0 == 0 && n < kQuadPre) ? ql.it[n].meta : quad_item<CHECK, FT>(u, H, W, wave, lane, k0 + n).meta;
-        if ((k0 + n < ipw) & ((meta >> 16) & 1u)) {
-            float4 *dst = s4 + (meta & 0xFFFu);
+        if ((k0 + n < ipw) & ((meta >> 17) & 1u)) {
+            float4 *dst = s4 + (meta & 0x1FFFu);
             unsigned m = 0xFu;
-            if (CHECK) m = ((meta >> 17) & 1u) ? (meta >> 12) & 0xFu : 0u;
+            if (CHECK) m = ((meta >> 18) & 1u) ? (meta >> 13) & 0xFu : 0u;
             const f32x4 w0 = QuadRaw<FT>::widen(r.a[n][0]), w1 = QuadRaw<FT>::widen(r.a[n][1]), w2 = QuadRaw<FT>::widen(r.a[n][2]),
                         w3 = QuadRaw<FT>::widen(r.a[n][3]);
 #pragma unroll

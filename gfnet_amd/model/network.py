@@ -84,7 +84,14 @@ class ConvRefiner(nn.Module):
         self.fold_out_conv = True  # multiply out_conv into the last block's 1x1 conv (see folded_stack)
 
     supports_reuse_d = True  # forward(..., reuse_d=): see GFNet.forward_pyramids
-    last_d = None
+
+    def may_reuse_d(self, x, y, flow):
+        """The previous iteration's concat tensor may be overwritten in place (through raw pointers: autograd's version counter
+        never sees the write) only when it cannot sit in an autograd graph: block1 saves `d` for its weight gradients whenever
+        grad mode is on and anything upstream or in this refiner asks for gradients."""
+        if not torch.is_grad_enabled():
+            return True
+        return not (x.requires_grad or y.requires_grad or flow.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def assemble(self, num_grid, x, y, flow, scale_factor=1, reuse=None):
         """d = cat(grid_feature, x_hat, disp_emb, local_corr) (network.py:555) and the local_corr view.
@@ -95,11 +102,9 @@ class ConvRefiner(nn.Module):
         dd = self.disp_emb.weight.shape[0]
         use_corr = bool(self.corr_in_other)
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or self.disp_emb.weight.requires_grad):
-            self.last_d = None
             return self._assemble_autograd(num_grid, x, y, flow, scale_factor)
         d = ops.refiner_input(num_grid, x, y, flow, self.disp_emb.weight, self.disp_emb.bias,
                               self.local_corr_radius if use_corr else 0, scale_factor=scale_factor, corr_in_other=use_corr, reuse=reuse)
-        self.last_d = d  # GFNet.forward_pyramids hands it back for the next iteration at the same scale
         return d, (d[:, 2 * c + dd:] if use_corr else None)
 
     def _assemble_autograd(self, num_grid, x, y, flow, scale_factor):
@@ -199,9 +204,16 @@ class ConvRefiner(nn.Module):
         return x if out_conv is None else ops.pointwise_conv(x, out_conv[0], out_conv[1])
 
     def forward(self, num_grid, x, y, flow, scale_factor=1, logits=None, reuse_d=None):
-        """reuse_d (not in the reference): the concat tensor of the previous call when x and num_grid are unchanged -- the
-        second iteration at a scale (network.py:257-268); saves regathering grid_feature.  Results are identical."""
-        d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor, reuse=reuse_d)
+        """reuse_d (not in the reference): a one-element list owned by the caller's loop over the iterations at one scale
+        (network.py:257-268).  It holds the concat tensor of the previous iteration -- same x, same num_grid -- whose grid_feature
+        planes are kept instead of regathered (results identical), and receives this call's.  The slot lives in the caller's
+        frame, not on the module: two host threads driving one model cannot pick up each other's tensor; and it is only filled
+        when the tensor cannot be part of an autograd graph (may_reuse_d)."""
+        prev = reuse_d[0] if reuse_d is not None else None
+        reusable = reuse_d is not None and self.may_reuse_d(x, y, flow)
+        d, local_corr = self.assemble(num_grid, x, y, flow, scale_factor, reuse=prev if reusable else None)
+        if reuse_d is not None:
+            reuse_d[0] = d if reusable else None
         if self._hip_stack_supported():
             out = self.conv_stack(d)
         else:
@@ -300,16 +312,14 @@ class GFNet(nn.Module):
             for itr in range(num_itr[idx]):
                 ref = self.conv_refiner[scale]
                 # later iterations at a scale see the same features and grid: the refiner keeps the grid_feature planes of
-                # its previous concat tensor (ConvRefiner.forward, reuse_d) instead of regathering them
-                prev_d = getattr(ref, "last_d", None) if (itr > 0 and getattr(ref, "supports_reuse_d", False)) else None
-                if prev_d is not None:
-                    d_flow, d_cert, _ = ref(num_grid[idx], f0, f1, flow, scale_factor=scale_factor, reuse_d=prev_d)
+                # its previous concat tensor (ConvRefiner.forward, reuse_d) instead of regathering them.  The slot is a local
+                # of this loop (never module state) and dies with the scale.
+                if itr == 0:
+                    d_slot = [None] if (num_itr[idx] > 1 and getattr(ref, "supports_reuse_d", False)) else None
+                if d_slot is not None:
+                    d_flow, d_cert, _ = ref(num_grid[idx], f0, f1, flow, scale_factor=scale_factor, reuse_d=d_slot)
                 else:
-                    if hasattr(ref, "last_d"):
-                        ref.last_d = None
                     d_flow, d_cert, _ = ref(num_grid[idx], f0, f1, flow, scale_factor=scale_factor)
-                if itr + 1 == num_itr[idx] and hasattr(ref, "last_d"):
-                    ref.last_d = None  # do not keep the scale's concat tensor alive
                 # each iteration's result is kept (corresps): out-of-place update straight from the refiner's outputs
                 flow, certainty = ops.flow_update(flow, certainty, d_flow, d_cert, disp_prev, int(scale), W0, H0,
                                                   zero_small=not self.training, first_iteration=(itr == 0))  # :262-268

@@ -24,6 +24,10 @@ kernel_events = None
 kernel_counters = None
 # the kernels read fp16 feature maps directly (BASELINE config 5): no widened copy is made
 NATIVE_FP16 = True
+# refiner_input writes the tile plan of the local correlation that follows it from extra workgroups of its own launch.  bench.py
+# switches this off for a few untimed steps so that the plan becomes the correlation call's own first launch and lands inside its
+# event bracket (`roofline.frac_incl_plan`).
+FUSE_PLAN = True
 
 
 def _timed(name, launch):
@@ -114,7 +118,7 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
     mode = (1 if symmetric else 0) | (2 if keep else 0)  # include/gfnet_hip.h: GFN_RI_KEEP_GRID_FEATURE
     disp_scale = float(40 / 32 * scale_factor)
     # shapes the lean local-correlation path takes are planned inside the refiner-input launch (both only read the flow)
-    plans = corr_in_other and bool(_L().gfn_local_corr_plans(C, Hs, Ws, G, r, dtx))
+    plans = FUSE_PLAN and corr_in_other and bool(_L().gfn_local_corr_plans(C, Hs, Ws, G, r, dtx))
     if corr_in_other:
         nscr = int(_L().gfn_local_corr_scratch_bytes(B, G))
         scr = _lib.scratch(dev, nscr)

@@ -30,10 +30,11 @@ def host(t):
 def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
     """672- and 224-sized pyramids (not 448 pyramids in a bigger image) through forward_pyramids of both passes with the
     refiner iterations of map.json; every flow / certainty the loop produces against the oracle's, then match_post."""
-    import bench
+    from gfnet_amd import _synthetic as synthetic
+    from oracle.scene import cpu_pair
 
     dev = torch.device("cuda", 0)
-    sc = bench.Scene(size, 1, num_itr, dtype, "off", dev, rank=0)
+    sc = synthetic.Scene(size, 1, num_itr, dtype, "off", dev, rank=0)
     m = sc.model
     with torch.inference_mode():
         m.train(False)
@@ -46,7 +47,7 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
     to_np = lambda p: {s: t.float().cpu().numpy() for s, t in p.items()}  # noqa: E731
     np_gt = {G: t.cpu().numpy() for G, t in sc.gt.items()}
     np_noise = {G: [n.numpy() for n in ns] for G, ns in sc.noise.items()}
-    r1, r2, warp_o, cert_o = sc.cpu_pair(0, (to_np(sc.pyr[0]), to_np(sc.pyr[1])), (to_np(sc.pyr_up[0]), to_np(sc.pyr_up[1])), np_gt,
+    r1, r2, warp_o, cert_o = cpu_pair(sc, 0, (to_np(sc.pyr[0]), to_np(sc.pyr[1])), (to_np(sc.pyr_up[0]), to_np(sc.pyr_up[1])), np_gt,
                                          np_noise, seed=0, return_all=True)
     # The eval-time rule of network.py:264-265 zeroes a displacement that repeats the previous one to 1e-6: discontinuous, and
     # with the stand-in refiner (displacements = differences of nearby floats, a few thousand representable values) a handful
@@ -61,7 +62,7 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
         return amb
 
     last_amb = None
-    for res, corr, sz, scales in ((r1, cor, size, bench.SCALES), (r2, cup, sc.up, bench.SCALES[1:])):
+    for res, corr, sz, scales in ((r1, cor, size, synthetic.SCALES), (r2, cup, sc.up, synthetic.SCALES[1:])):
         for s in scales:
             for itr in corr[s]:
                 last_amb = check(corr[s][itr]["flow"], res[(s, itr)][0], res[(s, itr)][2], f"{sz}: flow {s}.{itr}")
@@ -75,11 +76,11 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
 
 def _bench_flows(B, G, S, seed):
     """Flows like the bench's: true warps of 15 % corner-perturbation homographies (both directions) + 0.25-px noise."""
-    import bench
+    from gfnet_amd import _synthetic as synthetic
 
     gen = torch.Generator().manual_seed(seed)
-    H = bench.random_homographies(B // 2, S, gen)
-    f = torch.cat((bench.warp_grid(H, G, S, "cpu"), bench.warp_grid(np.linalg.inv(H), G, S, "cpu"))).permute(0, 3, 1, 2)
+    H = synthetic.random_homographies(B // 2, S, gen)
+    f = torch.cat((synthetic.warp_grid(H, G, S, "cpu"), synthetic.warp_grid(np.linalg.inv(H), G, S, "cpu"))).permute(0, 3, 1, 2)
     f = f + torch.randn(B, 2, G, G, generator=gen) * (0.5 / S)
     return f.contiguous().numpy().astype(np.float32)
 
@@ -98,9 +99,11 @@ def test_full_batch_local_correlation_vs_oracle(c, hs, G, r, S):
     out = local_correlation((B, c, hs, hs), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G, flow=torch.from_numpy(flow).cuda())
     ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
     assert_close(host(out), ref, 1e-4, f"full batch c{c} hs{hs} G{G} r{r}")
-    old = local_correlation((B, c, hs, hs), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G, flow=torch.from_numpy(flow).cuda(),
-                            _variant=2)
-    np.testing.assert_array_equal(host(out), host(old))
+    args = ((B, c, hs, hs), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G)
+    old = local_correlation(*args, flow=torch.from_numpy(flow).cuda(), _variant=2)
+    lean = local_correlation(*args, flow=torch.from_numpy(flow).cuda(), _variant=4)  # round-2 lean kernel: fp32 FMA D-stage
+    np.testing.assert_array_equal(host(lean), host(old))
+    assert_close(host(out), host(old), 1e-4, "default path (matrix-core D-stage where enabled) vs the fp32 FMA kernels")
 
 
 @pytest.mark.parametrize("G,S", [(48, 672), (96, 672), (192, 672), (384, 672), (16, 224), (32, 224), (64, 224), (128, 224)])

@@ -107,3 +107,26 @@ def test_gfnet_builds_from_basic_config_shapes():
     assert m.upsample_grids(560) == ([40, 80, 160, 320], [6, 4, 2, 0], [1, 1, 1, 1])
     with pytest.raises(NotImplementedError):
         m.extract_features(torch.zeros(2, 3, 448, 448))
+
+
+def test_concat_tensor_is_reused_only_outside_autograd_graphs():
+    """the second iteration at a scale overwrites the previous concat tensor `d` in place through raw pointers.
+    That is only allowed when `d` cannot be saved for a backward pass: grad mode off, or nothing upstream / in the refiner
+    asks for gradients.  The slot is the caller's (a list handed through forward), never module state."""
+    import torch
+
+    from gfnet_amd.model.network import ConvRefiner
+
+    ref = ConvRefiner(24, 24, 3, kernel_size=5, dw=True, hidden_blocks=1, displacement_emb="linear", displacement_emb_dim=4,
+                      local_corr_num=0, corr_in_other=False)
+    x, y, flow = torch.zeros(1, 10, 4, 4), torch.zeros(1, 10, 4, 4), torch.zeros(1, 2, 4, 4)
+    assert not hasattr(ref, "last_d")
+    with torch.no_grad():
+        assert ref.may_reuse_d(x, y, flow)
+    assert not ref.may_reuse_d(x, y, flow)              # trainable conv blocks: block1 would save d
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    assert ref.may_reuse_d(x, y, flow)                  # frozen refiner, detached inputs
+    assert not ref.may_reuse_d(x, y, flow.clone().requires_grad_(True))
+    ref.out_conv.weight.requires_grad_(True)
+    assert not ref.may_reuse_d(x, y, flow)

@@ -109,8 +109,10 @@ def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
                                       (32, 168, 96, 4), (16, 336, 192, 2)])
 @pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random", "border", "rot"])
 def test_lean_tile_kernel_is_bit_identical_to_round1_kernel(c, hs, G, r, flow_kind):
-    """The round-2 lean tile kernel (variant 0, r <= 4) keeps the round-1 kernel's arithmetic (same D accumulation order, same
-    epilogue): the two must agree bit for bit, whatever path a tile takes (staged, second launch, per-tap, empty windows)."""
+    """The round-2 lean tile kernel (variant 4, r <= 4) keeps the round-1 kernel's arithmetic (same D accumulation order, same
+    epilogue): the two must agree bit for bit, whatever path a tile takes (staged, second launch, per-tap, empty windows).
+    Round 3: where the default path (variant 0) runs the D-stage on the matrix core (split-bf16 operands, csrc/local_corr_mm.h)
+    it is a different numerics class: within the tolerance of the fp32 FMA kernels and of the oracle, on every flow kind."""
     B = 4
     f0 = synth.lattice_normalish((B, c, G, G), 231 + r)
     f1 = synth.lattice_normalish((B, c, hs, hs), 232 + r)
@@ -132,11 +134,13 @@ def test_lean_tile_kernel_is_bit_identical_to_round1_kernel(c, hs, G, r, flow_ki
             flow[b, 0] = (np.cos(a) * gx - np.sin(a) * gy) * 0.9
             flow[b, 1] = (np.sin(a) * gx + np.cos(a) * gy) * 0.9
         flow += np.float32(0.002) * synth.lattice_uniform((B, 2, G, G), 237)
-    lean = run(f0, f1, flow, r, G)
+    lean = run(f0, f1, flow, r, G, _variant=4)
     old = run(f0, f1, flow, r, G, _variant=2)
     np.testing.assert_array_equal(lean, old)
-    if flow_kind in ("border", "rot"):
-        assert_close(lean, oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
+    default = run(f0, f1, flow, r, G)
+    assert_close(default, lean, TOL, f"default path vs fp32 FMA kernels, {flow_kind}")
+    if flow_kind in ("border", "rot") or not np.array_equal(default, lean):
+        assert_close(default, oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
 
 
 def test_ragged_sizes_and_rect_maps():

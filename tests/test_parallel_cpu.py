@@ -73,3 +73,39 @@ def test_single_process_is_a_no_op():
 
     H = torch.eye(3, dtype=torch.float64)[None]
     assert parallel.gather_homographies(H) is H
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_starts_its_own_ranks_when_typed_as_a_bare_command():
+    """`python bench.py --gpus 2` without torchrun (WORLD_SIZE unset): the parent starts two rank processes, gloo stands in for
+    RCCL, no kernels run (--dry-run); exactly ONE JSON line comes back, from rank 0, and it saw both ranks."""
+    rc, js, err = _bench("--gpus", "2", "--backend", "gloo", "--dry-run")
+    assert rc == 0, err
+    assert len(js) == 1
+    assert js[0]["n_gpus"] == 2 and js[0]["n_ranks_seen"] == 2 and js[0]["gather_ok"] is True
+
+
+def test_bench_under_a_launcher_does_not_relaunch():
+    """With RANK / WORLD_SIZE already in the environment (torch.distributed.run) bench.py is a rank, not a launcher: a
+    world of one given by the environment runs in place."""
+    rc, js, err = _bench("--gpus", "1", "--dry-run", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert rc == 0, err
+    assert len(js) == 1 and js[0]["n_gpus"] == 1
+
+
+def test_bench_child_failure_is_the_parents_return_code():
+    """--gpus 2 given to ranks whose environment says WORLD_SIZE=1 must fail loudly (a mismatch is never papered over)."""
+    rc, js, err = _bench("--gpus", "2", "--dry-run", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert rc != 0 and not js

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+from gfnet_amd import _synthetic as bench  # noqa: E402
 from gfnet_amd import ops  # noqa: E402
 
 wl_key = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "448b32"
