@@ -70,6 +70,7 @@ struct LcParams {
     int *todo;                        // [kTodoHdr + B*tiles]: header (see kTodoHdr), then the ids of the tiles left to the second launch
     long todo_ints;
     int planned;                      // lean path: the plan is already in scratch (gfn_refiner_input_plan_fwd_dt wrote it)
+    int mm;                           // the plan is for / the tiles go to the matrix-core kernel (local_corr_mm.h) where Lean<R>::kMM
     int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
@@ -854,20 +855,6 @@ void lean_window_params(LcParams &p) {
     p.win_ystep = (p.win_yhi - ylo) / n1;
 }
 
-template <int R, int NCH, typename FT>
-void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, bool mm) {
-    if constexpr (Lean<R>::kMM) {
-        if (mm) {  // D-stage on the matrix core (local_corr_mm.h)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_mm_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kMaxLds);
-            hipLaunchKernelGGL((local_corr_tile_mm_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
-            return;
-        }
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
-}
-
 // compute units of the current device (queried once per device: hipGetDeviceProperties is slow)
 int device_cu_count() {
     static int cache[64] = {0};
@@ -881,8 +868,24 @@ int device_cu_count() {
     return cache[dev];
 }
 
+template <int R, int NCH, typename FT>
+void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+    if constexpr (Lean<R>::kMM) {
+        if (p.mm) {  // D-stage on the matrix core (local_corr_mm.h): one 16-wave workgroup per CU
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mm1_kernel<R, 16 * NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kMmLds);
+            // persistent: one workgroup per CU walks its share of the tiles
+            const unsigned cus = (unsigned)device_cu_count();
+            hipLaunchKernelGGL((local_corr_mm1_kernel<R, 16 * NCH, FT>), dim3(total < cus ? total : cus), dim3(kMmThreads), kMmLds, stream, p);
+            return;
+        }
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
+}
+
 template <int R, int ROUNDS, typename FT>
-int launch_tile(const LcParams &p0, hipStream_t stream, bool lean, bool mm) {
+int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
@@ -915,12 +918,12 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean, bool mm) {
                 if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
             }
             switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream, mm); break;
-                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream, mm); break;
-                default: launch_lean<R, 4, FT>(p, total, lds2, stream, mm); break;
+                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
+                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
+                default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
             }
             if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
-            if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
+            if (lean_workers<R>() > 0 && !(Lean<R>::kMM && p.mm)) return GFN_OK;  // its first workgroups are the second launch
         }
     }
     if (!(lean && ROUNDS == 2)) {
@@ -994,7 +997,7 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
     // to variant 2; kept as the cross-check of the matrix-core kernel)
     const bool planned = (variant & 8) != 0;  // gfn_refiner_input_plan_fwd_dt has already written this call's plan
     variant &= ~8;
-    const bool mm = variant == 0;
+    p.mm = variant == 0 ? 1 : 0;
     if (variant == 4) variant = 0;
     bool lean = variant == 0 && flow && !grid_based && win_h == H && win_w == W && lean_shape(C, H, W, G, r, p.f16);
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
@@ -1009,23 +1012,23 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
         int rc = -1000;
         if (p.f16) {
             switch (r) {
-                case 1: rc = launch_tile<1, 2, _Float16>(p, s, lean, mm); break;
-                case 2: rc = launch_tile<2, 2, _Float16>(p, s, lean, mm); break;
-                case 3: rc = launch_tile<3, 2, _Float16>(p, s, lean, mm); break;
-                case 4: rc = launch_tile<4, 2, _Float16>(p, s, lean, mm); break;
-                case 5: rc = launch_tile<5, 1, _Float16>(p, s, lean, mm); break;
-                case 6: rc = launch_tile<6, 1, _Float16>(p, s, lean, mm); break;
-                case 7: rc = launch_tile<7, 1, _Float16>(p, s, lean, mm); break;
+                case 1: rc = launch_tile<1, 2, _Float16>(p, s, lean); break;
+                case 2: rc = launch_tile<2, 2, _Float16>(p, s, lean); break;
+                case 3: rc = launch_tile<3, 2, _Float16>(p, s, lean); break;
+                case 4: rc = launch_tile<4, 2, _Float16>(p, s, lean); break;
+                case 5: rc = launch_tile<5, 1, _Float16>(p, s, lean); break;
+                case 6: rc = launch_tile<6, 1, _Float16>(p, s, lean); break;
+                case 7: rc = launch_tile<7, 1, _Float16>(p, s, lean); break;
             }
         } else {
             switch (r) {
-                case 1: rc = launch_tile<1, 2, float>(p, s, lean, mm); break;
-                case 2: rc = launch_tile<2, 2, float>(p, s, lean, mm); break;
-                case 3: rc = launch_tile<3, 2, float>(p, s, lean, mm); break;
-                case 4: rc = launch_tile<4, 2, float>(p, s, lean, mm); break;
-                case 5: rc = launch_tile<5, 1, float>(p, s, lean, mm); break;
-                case 6: rc = launch_tile<6, 1, float>(p, s, lean, mm); break;
-                case 7: rc = launch_tile<7, 1, float>(p, s, lean, mm); break;
+                case 1: rc = launch_tile<1, 2, float>(p, s, lean); break;
+                case 2: rc = launch_tile<2, 2, float>(p, s, lean); break;
+                case 3: rc = launch_tile<3, 2, float>(p, s, lean); break;
+                case 4: rc = launch_tile<4, 2, float>(p, s, lean); break;
+                case 5: rc = launch_tile<5, 1, float>(p, s, lean); break;
+                case 6: rc = launch_tile<6, 1, float>(p, s, lean); break;
+                case 7: rc = launch_tile<7, 1, float>(p, s, lean); break;
             }
         }
         if (rc != -1000) return rc;  // -1000: shape not supported by the tiled path
@@ -1086,6 +1089,7 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
     p.todo = reinterpret_cast<int *>(scratch);
     p.plan = lean_plan_ptr(scratch, B, G);
+    p.mm = 1;  // the plan is for the default path of the call that follows (variant 8)
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == GFN_F16;
     switch (r) {

@@ -23,6 +23,12 @@
 //   * tile = two 4 x 8-cell halves (cells 0-31 / 32-63), the epilogue still stores 64-byte row segments;
 //   * fraction table: lane = cell, wave = tap index (no division); stores use scalar plane offsets.
 
+constexpr int kMmNBW = 10;  // local_corr_mm.h: accumulator blocks per wave of the matrix-core kernel (a group's box: <= 2 kMmNBW rows)
+template <int R> __device__ __forceinline__ bool mm_region_fits_rt(int w, int h, int C);  // local_corr_mm.h
+
+#ifndef GFN_MM_DEFAULT
+#define GFN_MM_DEFAULT 0
+#endif
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
@@ -44,10 +50,7 @@ struct Lean {
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
-    // matrix-core D-stage (local_corr_mm.h): a group of 2 x 8 cells is served by two waves, one per 16-position column tile of
-    // the group's window box, each holding at most NBW rows of 16 x 16 accumulator blocks
-    static constexpr bool kMM = false;  // round 3, first cut (2 workgroups x 8 waves, 16-channel chunks): 64 accumulators per wave spill; see local_corr_mm.h
-    static constexpr int NBW = 16;
+    static constexpr bool kMM = GFN_MM_DEFAULT && (R == 3 || R == 4);  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
@@ -146,7 +149,7 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
         // of the tile (their union)
         const int rx0 = row_min_i32(c.bx0), ry0 = row_min_i32(c.by0), rx1 = row_min_i32(-c.bx1), ry1 = row_min_i32(-c.by1);
         int hx0[2], hy0[2], hx1[2], hy1[2];
-        bool mm_ok = true;  // every group's box fits two 16-position column tiles x NBW rows (the matrix-core D-stage's accumulators)
+        bool mm_ok = true;  // matrix-core kernel: every group's box fits two 16-position column tiles x 2 kMmNBW rows (its accumulators)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             int gx0[2], gy0[2], gx1[2], gy1[2];
@@ -157,7 +160,7 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 gy0[k] = __builtin_amdgcn_readlane(ry0, l15);
                 gx1[k] = -__builtin_amdgcn_readlane(rx1, l15);
                 gy1[k] = -__builtin_amdgcn_readlane(ry1, l15);
-                if (Lean<R>::kMM && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= Lean<R>::NBW);
+                if (Lean<R>::kMM && p.mm && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= 2 * kMmNBW);
             }
             hx0[h] = min(gx0[0], gx0[1]); hy0[h] = min(gy0[0], gy0[1]);
             hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
@@ -183,8 +186,24 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
                 return region_fits<R>(u);
             };
+            if (Lean<R>::kMM && p.mm) {
+                // the matrix-core kernel's plan: ONE region (its stage holds ~1100 positions: no halves mode), the same start
+                // alignment rule, no pitch padding (its slots are swizzled); what does not fit goes to the second launch's list
+                const int bx0 = min(hx0[0], hx0[1]), by0 = min(hy0[0], hy0[1]), bx1 = max(hx1[0], hx1[1]), by1 = max(hy1[0], hy1[1]);
+                int x0 = p.f16 ? (bx0 & ~1) : bx0;
+                const int xa = bx0 & ~3;
+                if (!all_in || ((p.W & 3) == 0 && ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2))) x0 = xa;
+                int w = max(bx1 - x0, 0), h = max(by1 - by0, 0), y0 = by0;
+                if (w == 0 || h == 0) { x0 = 0; y0 = 0; w = 0; h = 0; }
+                const bool fits = mm_ok && mm_region_fits_rt<R>(w, h, p.C);
+                const int flags = (all_in ? kPlanInterior : 0) | (fits ? 0 : kPlanSecond);
+                reinterpret_cast<int4 *>(p.plan)[2 * wid] = make_int4(x0, y0, (h << 16) | w, flags);
+                reinterpret_cast<int4 *>(p.plan)[2 * wid + 1] = make_int4(0, 0, 0, 0);
+                if (!fits) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;
+                continue;
+            }
             RowPlan ua, ub;
-            const bool border_ok = mm_ok;
+            const bool border_ok = true;
             int flags = all_in ? kPlanInterior : 0;
             const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
             ub = ua;
@@ -280,6 +299,7 @@ struct QuadRegs {
     typename QuadRaw<FT>::type a[N][4];  // [item][channel of the quad] -> 4 pixels, as loaded (fp16 is widened at the commit)
 };
 
+constexpr unsigned kOffRange = 0x7FFFFFF0u;  // a voffset no descriptor of ours covers (planes are < 2^30 bytes)
 constexpr int kQuadPre = 2;  // work items of a chunk in flight per wave (regions needing more per wave finish them in a loop)
 struct QuadItem {
     unsigned voff;        // byte offset of the lane's quad: (row * W + x) elements + the channel quad's four planes
@@ -292,7 +312,7 @@ struct QuadLane {         // per lane and region, the first kQuadPre items of th
 };
 
 // item k of wave `wave`: where the lane's quad comes from and where it goes
-template <bool CHECK, typename FT, int UNIT = kSlotV4>
+template <bool CHECK, typename FT, int UNIT = kSlotV4, bool OOR = false>
 __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, int wave, int lane, int k) {
     constexpr unsigned ES = sizeof(FT);
     const int cg = (lane >> 2) & 3;
@@ -301,7 +321,7 @@ __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, in
     int row = (int)(((float)L + 0.5f) * inv_nq);      // L / nq, exact for these sizes (L < 1024)
     int q = L - row * u.nq;
     const bool have = row < u.h;
-    if (!have) row = 0, q = 0;                        // idle lanes repeat the region's first quad (a valid address)
+    if (!have) row = 0, q = 0;                        // idle lanes: the slot arithmetic below stays in range, the load is switched off
     const int x = u.x0 + 4 * q;
     unsigned xmask = 0;
 #pragma unroll
@@ -312,12 +332,15 @@ __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, in
     // border tiles: x0 is a multiple of 4 (plan launch), so a quad never straddles the left image edge; quads left of the image
     // and rows outside it point at a pixel inside and are zeroed at the commit, like the pixels that hang over the right edge
     const int px = CHECK ? (row_in ? gy : 0) * W + max(x, 0) : row * W + x;  // !CHECK: relative to the region's first row
-    o.voff = (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES;
+    // idle lanes ask for an offset past the descriptor's range: the buffer load returns zeros without a memory access (a repeated
+    // valid address cost a full trip through the texture-address path, which is what the tile kernels queue for)
+    // (OOR: the r >= 3 kernels; the r <= 2 kernels live on 80 registers and the extra select spills: they keep the repeated address)
+    o.voff = (have || !OOR) ? (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES : kOffRange;
     o.meta = (unsigned)((row * u.pitch + 4 * q) * UNIT + cg) | (xmask << 13) | (have ? 1u << 17 : 0u) | (row_in ? 1u << 18 : 0u);
     return o;
 }
 
-template <int N, bool CHECK, typename FT, int UNIT = kSlotV4>
+template <int N, bool CHECK, typename FT, int UNIT = kSlotV4, bool OOR = false>
 __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave,
                                            int lane, const QuadLane &ql, int k0) {
     constexpr unsigned ES = sizeof(FT);
@@ -329,8 +352,8 @@ __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsig
     for (int n = 0; n < N; ++n) {
         // no branch around the loads: an item past the wave's last one repeats the last one (L1 hits, result unused)
         unsigned vo;
-        if (k0 == 0 && n < kQuadPre) vo = (n == 0 || n < ipw) ? ql.it[n].voff : ql.it[0].voff;
-        else vo = quad_item<CHECK, FT, UNIT>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
+        if (k0 == 0 && n < kQuadPre) vo = (n == 0 || n < ipw) ? ql.it[n].voff : (OOR ? kOffRange : ql.it[0].voff);
+        else vo = quad_item<CHECK, FT, UNIT, OOR>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
     }
@@ -453,14 +476,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     auto quad_lane = [&](const RowPlan &u) {
         QuadLane ql;
 #pragma unroll
-        for (int n = 0; n < kQuadPre; ++n) ql.it[n] = quad_item<CHECK, FT>(u, H, W, wave, lane, n);
+        for (int n = 0; n < kQuadPre; ++n) ql.it[n] = quad_item<CHECK, FT, kSlotV4, (R >= 3)>(u, H, W, wave, lane, n);
         return ql;
     };
     const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
     constexpr int PRE = kQuadPre;
     QuadRegs<PRE, FT> pre;
-    quad_issue<PRE, CHECK, FT>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
+    quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
@@ -552,7 +575,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) quad_issue<PRE, CHECK, FT>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);  // next step's loads: in flight across this D-stage
+        if (more) quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);  // next step's loads: in flight across this D-stage
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
