@@ -164,6 +164,35 @@ def dry_run(args):
     return 0 if ok else 1
 
 
+class SceneRunner:
+    """One step of every scene.  Scenes are independent (different image sizes of the pyramid workload): each runs on a HIP stream
+    of its own so that the small scene's 16-64-workgroup launches overlap the large scene's wide ones (scratch is keyed by stream,
+    gfnet_amd/_lib.py); a single scene stays on the current stream."""
+
+    def __init__(self, scenes):
+        import torch
+
+        self.scenes = scenes
+        self.streams = [torch.cuda.Stream() for _ in scenes] if len(scenes) > 1 else None
+
+    def step(self, seed):
+        import torch
+
+        if self.streams is None:
+            return [sc.step(seed) for sc in self.scenes]
+        main = torch.cuda.current_stream()
+        outs = []
+        for sc, st in zip(self.scenes, self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(sc.step(seed))
+        for o, st in zip(outs, self.streams):
+            main.wait_stream(st)
+            for t in o:
+                t.record_stream(main)
+        return outs
+
+
 def secondary_workload(key, conv_stack, dev, rank, steps):
     """A few steps of another BASELINE configuration after the timed region of the default line (configs[2] and
     configs[4] were builder-run only): whole-step rate and the roofline fraction of its own scale-4 local-correlation call."""
@@ -178,16 +207,15 @@ def secondary_workload(key, conv_stack, dev, rank, steps):
     with torch.inference_mode(False):
         scenes = [Scene(S, wl["pairs"], wl["num_itr"], dtype, conv_stack, dev, rank) for S in wl["sizes"]]
     main_scene = scenes[min(1, len(scenes) - 1)]
+    runner = SceneRunner(scenes)
     with torch.inference_mode():
         for i in range(2):
-            for sc in scenes:
-                sc.step(i)
+            runner.step(i)
         torch.cuda.synchronize()
         ops.kernel_events = {main_scene.roofline_key: []}
         t0 = time.perf_counter()
         for i in range(steps):
-            for sc in scenes:
-                sc.step(0)
+            runner.step(0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         events = ops.kernel_events[main_scene.roofline_key]
@@ -234,8 +262,10 @@ def main():
     main_scene = scenes[min(1, len(scenes) - 1)] if len(scenes) > 1 else scenes[0]  # the 448 scene of the pyramid workload
     pairs_per_step = B * len(scenes)
 
+    runner = SceneRunner(scenes)
+
     def step(seed):
-        outs = [sc.step(seed) for sc in scenes]
+        outs = runner.step(seed)
         Hl = torch.cat([o[0] for o in outs])
         return parallel.gather_homographies(Hl), outs
 
@@ -298,15 +328,14 @@ def main():
         if args.conv_stack == "off" and world == 1 and not args.no_stack_leg:
             with torch.inference_mode(False):  # module parameters must be ordinary tensors (the packed-parameter cache reads their versions)
                 scenes2 = [Scene(S, B, wl["num_itr"], dtype, "amp", dev, rank) for S in wl["sizes"]]
+            runner2 = SceneRunner(scenes2)
             for i in range(2):
-                for sc in scenes2:
-                    sc.step(i)
+                runner2.step(i)
             torch.cuda.synchronize()
             n2 = max(3, min(args.steps, 10))
             t1 = time.perf_counter()
             for i in range(n2):
-                for sc in scenes2:
-                    sc.step(0)
+                runner2.step(0)
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             stack_leg = {"value": round(pairs_per_step * n2 / dt2, 2), "unit": "pairs/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,

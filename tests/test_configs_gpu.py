@@ -25,16 +25,22 @@ def host(t):
     return t.detach().float().cpu().numpy()
 
 
-@pytest.mark.parametrize("size,num_itr,dtype", [(672, [2] * 5, torch.float32), (224, [2] * 5, torch.float32),
-                                                (224, [1] * 5, torch.float16), (672, [1, 2, 1, 2, 1], torch.float16)])
-def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
-    """672- and 224-sized pyramids (not 448 pyramids in a bigger image) through forward_pyramids of both passes with the
-    refiner iterations of map.json; every flow / certainty the loop produces against the oracle's, then match_post."""
+@pytest.mark.parametrize("size,num_itr,dtype,pairs", [(672, [2] * 5, torch.float32, 1), (224, [2] * 5, torch.float32, 1),
+                                                      (224, [1] * 5, torch.float16, 1), (672, [1, 2, 1, 2, 1], torch.float16, 1),
+                                                      (448, [1] * 5, torch.float32, 1), (448, [2] * 5, torch.float32, 1),
+                                                      (224, [1, 2, 1, 1, 2], torch.float32, 4)])
+def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype, pairs):
+    """672-, 448- and 224-sized pyramids (not 448 pyramids in a bigger image) through forward_pyramids of both passes with the
+    refiner iterations of map.json / basic.json; every flow / certainty the loop produces against the oracle's, then match_post.
+    448 is BASELINE configs[1]'s own loop (model/network.py:230-281, 326-349 at 448 / 560); the 4-pair case (8 directions)
+    checks the batch indexing of the whole loop: every pair against its own oracle walk.  Where a scale runs two iterations the
+    eval-time zeroing decision itself (network.py:264-265) is compared too: outside the band around the threshold no element
+    may be zeroed on the device that the oracle moved."""
     from gfnet_amd import _synthetic as synthetic
     from oracle.scene import cpu_pair
 
     dev = torch.device("cuda", 0)
-    sc = synthetic.Scene(size, 1, num_itr, dtype, "off", dev, rank=0)
+    sc = synthetic.Scene(size, pairs, num_itr, dtype, "off", dev, rank=0)
     m = sc.model
     with torch.inference_mode():
         m.train(False)
@@ -47,42 +53,46 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype):
     to_np = lambda p: {s: t.float().cpu().numpy() for s, t in p.items()}  # noqa: E731
     np_gt = {G: t.cpu().numpy() for G, t in sc.gt.items()}
     np_noise = {G: [n.numpy() for n in ns] for G, ns in sc.noise.items()}
-    r1, r2, warp_o, cert_o = cpu_pair(sc, 0, (to_np(sc.pyr[0]), to_np(sc.pyr[1])), (to_np(sc.pyr_up[0]), to_np(sc.pyr_up[1])), np_gt,
-                                         np_noise, seed=0, return_all=True)
+    npyr, nup = (to_np(sc.pyr[0]), to_np(sc.pyr[1])), (to_np(sc.pyr_up[0]), to_np(sc.pyr_up[1]))
+
     # The eval-time rule of network.py:264-265 zeroes a displacement that repeats the previous one to 1e-6: discontinuous, and
     # with the stand-in refiner (displacements = differences of nearby floats, a few thousand representable values) a handful
     # of cells per map repeat EXACTLY on one side and miss by one ulp on the other.  Those cells (rel within 10x of the
     # threshold in the oracle) are compared with the tolerance of one displacement instead; they must stay rare.
     def check(got, ref, rel, what):
-        got, ref = host(got), np.asarray(ref)
+        ref = np.asarray(ref)
         amb = (rel < 1e-5).any(axis=1, keepdims=True) & np.ones_like(ref, bool)
         assert amb.mean() < 1e-3, f"{what}: {amb.mean():.2e} of the cells sit on the zeroing threshold"
         assert_close(np.where(amb, ref, got), ref, 1e-4, what)
         assert np.abs(got - ref)[amb].max(initial=0) < 8.0 / size, what  # a flipped cell is off by one displacement (~ the flow noise)
         return amb
 
-    last_amb = None
-    for res, corr, sz, scales in ((r1, cor, size, synthetic.SCALES), (r2, cup, sc.up, synthetic.SCALES[1:])):
-        for s in scales:
-            for itr in corr[s]:
-                last_amb = check(corr[s][itr]["flow"], res[(s, itr)][0], res[(s, itr)][2], f"{sz}: flow {s}.{itr}")
-                assert_close(host(corr[s][itr]["certainty"]), res[(s, itr)][1], 1e-4, f"{sz}: cert {s}.{itr}")
-    # match_post: the cells that flipped in the very last update are excluded from the warp (both halves of the symmetric layout)
-    G = warp_o.shape[1]
-    amb_w = np.concatenate((last_amb[:1, 0], last_amb[1:, 0]), axis=2)[..., None] & np.ones_like(warp_o, bool)
-    assert_close(np.where(amb_w, warp_o, host(warp)), warp_o, 1e-4, "warp")
-    assert_close(np.where(amb_w[..., 0], cert_o, host(cert)), cert_o, 1e-4, "certainty")
-
-
-def _bench_flows(B, G, S, seed):
-    """Flows like the bench's: true warps of 15 % corner-perturbation homographies (both directions) + 0.25-px noise."""
-    from gfnet_amd import _synthetic as synthetic
-
-    gen = torch.Generator().manual_seed(seed)
-    H = synthetic.random_homographies(B // 2, S, gen)
-    f = torch.cat((synthetic.warp_grid(H, G, S, "cpu"), synthetic.warp_grid(np.linalg.inv(H), G, S, "cpu"))).permute(0, 3, 1, 2)
-    f = f + torch.randn(B, 2, G, G, generator=gen) * (0.5 / S)
-    return f.contiguous().numpy().astype(np.float32)
+    for b in range(pairs):
+        rows = [b, b + pairs]  # the pair's two directions in the symmetric batch
+        r1, r2, warp_o, cert_o = cpu_pair(sc, b, npyr, nup, np_gt, np_noise, seed=0, return_all=True)
+        last_amb = None
+        for res, corr, sz, scales in ((r1, cor, size, synthetic.SCALES), (r2, cup, sc.up, synthetic.SCALES[1:])):
+            for s in scales:
+                prev = None
+                for itr in corr[s]:
+                    got = host(corr[s][itr]["flow"])[rows]
+                    ref, rel = np.asarray(res[(s, itr)][0]), np.asarray(res[(s, itr)][2])
+                    last_amb = check(got, ref, rel, f"{sz} pair {b}: flow {s}.{itr}")
+                    assert_close(host(corr[s][itr]["certainty"])[rows], res[(s, itr)][1], 1e-4, f"{sz} pair {b}: cert {s}.{itr}")
+                    if prev is not None:
+                        # iteration >= 2: the zeroing decision itself.  An element is zeroed iff its displacement repeats the
+                        # previous one to 1e-6; seen from outside, a zeroed element's flow does not move.  Outside the band
+                        # around the threshold (oracle ratio > 1e-5: nothing is zeroed there -- inside it the two sides may
+                        # differ, see above, and an exact repeat, ratio 0, is the band's other edge) every element whose
+                        # oracle flow moved by more than a few ulps must have moved on the device as well, element for element.
+                        clear = (rel > 1e-5) & (np.abs(ref - prev[1]) > 1e-5)  # (a NaN ratio, 0 / 0, compares False)
+                        assert clear.mean() > 0.9, f"{sz} pair {b}: {s}.{itr}: the mask check would be vacuous"
+                        assert not np.any((got == prev[0])[clear]), f"{sz} pair {b}: zeroing mask {s}.{itr}"
+                    prev = (got, ref)
+        # match_post: the cells that flipped in the very last update are excluded from the warp (both halves of the symmetric layout)
+        amb_w = np.concatenate((last_amb[:1, 0], last_amb[1:, 0]), axis=2)[..., None] & np.ones_like(warp_o, bool)
+        assert_close(np.where(amb_w, warp_o, host(warp)[b:b + 1]), warp_o, 1e-4, f"pair {b}: warp")
+        assert_close(np.where(amb_w[..., 0], cert_o, host(cert)[b:b + 1]), cert_o, 1e-4, f"pair {b}: certainty")
 
 
 @pytest.mark.parametrize("c,hs,G,r,S", [(32, 112, 64, 4, 448), (16, 224, 128, 2, 448), (32, 168, 96, 4, 672)])
