@@ -836,6 +836,14 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
            (long)C * G * G < (1L << 30);
 }
 
+// shapes whose default path is the matrix-core kernel (local_corr_mm.h)
+bool mm_shape(int C, int H, int W, int G, int r, int f16) {
+    const bool kmm = r >= 5 ? r <= 7 : (GFN_MM_DEFAULT != 0 && (r == 3 || r == 4));
+    const long K = (long)(2 * r + 1) * (2 * r + 1);
+    return kmm && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
+           (long)C * G * G < (1L << 30);
+}
+
 // scratch layout of the lean path: header and tile list (ints), then the plan, 32-byte aligned
 int *lean_plan_ptr(void *scratch, int B, int G) {
     const int64_t tiles_max = (int64_t)((G + 1) / 2) * ((G + 15) / 16) * B;  // what gfn_local_corr_scratch_bytes sized the list for
@@ -870,22 +878,52 @@ int device_cu_count() {
 
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
-    if constexpr (Lean<R>::kMM) {
-        if (p.mm) {  // D-stage on the matrix core (local_corr_mm.h): one 16-wave workgroup per CU
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mm1_kernel<R, 16 * NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kMmLds);
-            // persistent: one workgroup per CU walks its share of the tiles
-            const unsigned cus = (unsigned)device_cu_count();
-            hipLaunchKernelGGL((local_corr_mm1_kernel<R, 16 * NCH, FT>), dim3(total < cus ? total : cus), dim3(kMmThreads), kMmLds, stream, p);
-            return;
-        }
-    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
 
+// the matrix-core path (local_corr_mm.h): plan (unless the refiner-input launch wrote it), the persistent tile kernel (one 16-wave
+// workgroup per CU), and the round-1 sub-tile routine for the tiles the plan listed (4 x 16-cell tiles re-cut into 4 x 8 halves)
+template <int R, typename FT>
+int launch_mm(const LcParams &p0, hipStream_t stream) {
+    LcParams p = p0;
+    lean_window_params<R>(p);
+    const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
+    if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
+    if (!p.planned) {
+        hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
+        if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
+    }
+    const unsigned cus = (unsigned)device_cu_count();
+    const dim3 grid(total < cus ? total : cus);
+#define GFN_MM_LAUNCH(CC)                                                                                                                  \
+    do {                                                                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mm1_kernel<R, CC, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  kMmLds);                                                                                                 \
+        hipLaunchKernelGGL((local_corr_mm1_kernel<R, CC, FT>), grid, dim3(kMmThreads), kMmLds, stream, p);                                 \
+    } while (0)
+    switch (p.C) {
+        case 16: GFN_MM_LAUNCH(16); break;
+        case 32: GFN_MM_LAUNCH(32); break;
+        default: GFN_MM_LAUNCH(64); break;
+    }
+#undef GFN_MM_LAUNCH
+    if (int e = gfn::check_launch("local_corr_mm1_kernel")) return e;
+    constexpr int NC = 64;
+    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
+                       (size_t)NC * (p.C + 4) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, 2, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kMaxLds);
+    const unsigned grid2 = total < 256 ? total : 256;
+    hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
+    return gfn::check_launch("local_corr_irregular_kernel");
+}
+
 template <int R, int ROUNDS, typename FT>
 int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
+    if constexpr (Lean<R>::kMM) {
+        if (lean && p0.mm) return launch_mm<R, FT>(p0, stream);
+    }
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
     p.tiles_x = (p.G + kTileW - 1) / kTileW;
@@ -923,7 +961,7 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
                 default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
             }
             if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
-            if (lean_workers<R>() > 0 && !(Lean<R>::kMM && p.mm)) return GFN_OK;  // its first workgroups are the second launch
+            if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
         }
     }
     if (!(lean && ROUNDS == 2)) {
@@ -997,9 +1035,11 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
     // to variant 2; kept as the cross-check of the matrix-core kernel)
     const bool planned = (variant & 8) != 0;  // gfn_refiner_input_plan_fwd_dt has already written this call's plan
     variant &= ~8;
-    p.mm = variant == 0 ? 1 : 0;
+    const bool want_mm = variant == 0;
     if (variant == 4) variant = 0;
-    bool lean = variant == 0 && flow && !grid_based && win_h == H && win_w == W && lean_shape(C, H, W, G, r, p.f16);
+    const bool tiled = variant == 0 && flow && !grid_based && win_h == H && win_w == W;
+    p.mm = (want_mm && tiled && mm_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
+    bool lean = tiled && (p.mm || lean_shape(C, H, W, G, r, p.f16));
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
     p.planned = planned ? 1 : 0;
     if (lean && scratch) {
@@ -1050,7 +1090,7 @@ GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f
 
 // ---- refiner input + plan in one launch ----------------------------------------------------------------------------------
 GFN_EXPORT int gfn_local_corr_plans(int C, int H, int W, int G, int r, int f1_dtype) {
-    return lean_shape(C, H, W, G, r, f1_dtype == GFN_F16) ? 1 : 0;
+    return (lean_shape(C, H, W, G, r, f1_dtype == GFN_F16) || mm_shape(C, H, W, G, r, f1_dtype == GFN_F16)) ? 1 : 0;
 }
 
 namespace {
@@ -1075,7 +1115,7 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G || ((symmetric & 1) && (B & 1)) ||
         (symmetric & ~3) || (long)C * Hs * Ws >= (1L << 31) || B > 65535 || (long)G * G >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: bad size");
-    if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
+    if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16) && !mm_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: the local correlation of this shape takes no plan (ask gfn_local_corr_plans first)");
     if (!scratch || scratch_bytes < gfn_local_corr_scratch_bytes(B, G) || ((uintptr_t)scratch & 3))
         return gfn::fail(GFN_ERR_SCRATCH, "refiner_input_plan: scratch too small");
@@ -1089,14 +1129,17 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
     p.todo = reinterpret_cast<int *>(scratch);
     p.plan = lean_plan_ptr(scratch, B, G);
-    p.mm = 1;  // the plan is for the default path of the call that follows (variant 8)
+    p.mm = mm_shape(C, Hs, Ws, G, r, dtype == GFN_F16) ? 1 : 0;  // the plan is for the default path of the call that follows (variant 8)
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == GFN_F16;
     switch (r) {
         case 1: return h ? launch_ri_plan<1, _Float16>(q, p, s, keep) : launch_ri_plan<1, float>(q, p, s, keep);
         case 2: return h ? launch_ri_plan<2, _Float16>(q, p, s, keep) : launch_ri_plan<2, float>(q, p, s, keep);
         case 3: return h ? launch_ri_plan<3, _Float16>(q, p, s, keep) : launch_ri_plan<3, float>(q, p, s, keep);
-        default: return h ? launch_ri_plan<4, _Float16>(q, p, s, keep) : launch_ri_plan<4, float>(q, p, s, keep);
+        case 4: return h ? launch_ri_plan<4, _Float16>(q, p, s, keep) : launch_ri_plan<4, float>(q, p, s, keep);
+        case 5: return h ? launch_ri_plan<5, _Float16>(q, p, s, keep) : launch_ri_plan<5, float>(q, p, s, keep);
+        case 6: return h ? launch_ri_plan<6, _Float16>(q, p, s, keep) : launch_ri_plan<6, float>(q, p, s, keep);
+        default: return h ? launch_ri_plan<7, _Float16>(q, p, s, keep) : launch_ri_plan<7, float>(q, p, s, keep);
     }
 }
 

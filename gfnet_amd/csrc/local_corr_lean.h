@@ -50,7 +50,9 @@ struct Lean {
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
-    static constexpr bool kMM = GFN_MM_DEFAULT && (R == 3 || R == 4);  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
+    // R >= 5 (GFNet: r = 6, 7 on 64-channel maps, 196 / 256 products per cell and channel): the matrix-core kernel is the default
+    // path; R = 3, 4 only in GFN_MM_DEFAULT builds (there the lean fp32 kernel, two workgroups per CU, is still faster)
+    static constexpr bool kMM = GFN_MM_DEFAULT && R >= 3;  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
@@ -449,66 +451,56 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #endif
     STAMP(0);
 
-    // ---- flow, the f0 block and the first chunk's stage loads all go out at once ------------------------------------------
-    // lane = cell id (cells 0-31 left half, 32-63 right half); every wave reads the 64 flows: wave 0 files the per-cell
-    // arrays, each wave derives its share of the fraction table from them in registers
+    // ---- flow (wave 0), the f0 block and the first chunk's stage loads all go out at once ---------------------------------------
+    // The tile kernels queue for the vector-memory pipe (a wave-load costs 30-40 cycles of the CU's texture-address path, and a
+    // tile issued ~180 of them): every load that is not needed is gone.  lane = cell id (cells 0-31 left half, 32-63 right half);
+    // only wave 0 reads the 64 flows and files the per-cell arrays; the fraction table is derived from those behind the barrier.
     const int my_gi = row0 + cell_row(lane), my_gj = col0 + cell_col(lane);
     const bool my_ok = (my_gi < G) & (my_gj < G);
-    float my_nx, my_ny;
-    {
+    float my_nx = 0.f, my_ny = 0.f;
+    if (wave == 0) {  // scalar
         const rsrc_t flr = make_rsrc(p.flow + (size_t)b * 2 * G * G, 2u * GG4);
         const unsigned fo = my_ok ? (unsigned)(my_gi * G + my_gj) * 4u : 0u;
         my_nx = buf_ld(flr, fo, 0u);
         my_ny = buf_ld(flr, fo, GG4);
     }
-    // the tile's f0 block: wave w takes channels w, w+8, ...; lane -> tile row lane >> 4, column lane & 15, so a load is four
-    // 64-byte row segments at scalar plane offset + the lane's grid offset
-    constexpr int NF0 = C / kWaves;
-    float f0v[NF0];
-    const int fr = lane >> 4, fc = lane & 15;
-    const bool fok = (row0 + fr < G) & (col0 + fc < G);
+    // the tile's f0 block: wave w takes channels w, w + 8, ...; one 16-byte load per lane = four consecutive cells of a grid row of
+    // one of them (lane >> 4 = which channel, lane & 15 = tile row and column quad): C / 32 loads per wave instead of C / 8
+    constexpr int NF0 = C / kWaves;              // channels per wave
+    constexpr int NF0L = (NF0 + 3) / 4;          // loads per wave
+    f32x4 f0q[NF0L];
+    const int fk = lane >> 4, fr = (lane & 15) >> 2, fq = lane & 3;
+    const bool f0_lane = fk < (NF0 < 4 ? NF0 : 4);
     {
-        const unsigned fgoff = fok ? (unsigned)((row0 + fr) * G + col0 + fc) * 4u : 0u;
+        const bool in = f0_lane & (row0 + fr < G) & (col0 + 4 * fq < G);
         const rsrc_t f0r = make_rsrc(p.f0 + (size_t)b * p.f0_bs, (unsigned)C * GG4);
 #pragma unroll
-        for (int k = 0; k < NF0; ++k) f0v[k] = buf_ld(f0r, fgoff, (unsigned)(wave + k * kWaves) * GG4);
+        for (int l = 0; l < NF0L; ++l) {
+            const int ch = wave + (4 * l + fk) * kWaves;
+            const unsigned fgoff = in ? (unsigned)((row0 + fr) * G + col0 + 4 * fq) * 4u + (unsigned)ch * GG4 : 0u;
+            f0q[l] = buf_ld4(f0r, fgoff, 0u);
+        }
     }
+    // items of a chunk in flight per wave.  r <= 2: the 40 KB stage holds 512 positions = 512 lane items of a 16-channel chunk = one
+    // item per lane, so a second register set only ever repeated the first item's loads -- half of the kernel's vector-memory
+    // instructions, each a full trip through the texture-address path
+    constexpr int PRE = (R <= 2 && Lean<R>::kCap <= 512) ? 1 : kQuadPre;
     auto quad_lane = [&](const RowPlan &u) {
         QuadLane ql;
 #pragma unroll
-        for (int n = 0; n < kQuadPre; ++n) ql.it[n] = quad_item<CHECK, FT, kSlotV4, (R >= 3)>(u, H, W, wave, lane, n);
+        for (int n = 0; n < PRE; ++n) ql.it[n] = quad_item<CHECK, FT, kSlotV4, (R >= 3)>(u, H, W, wave, lane, n);
         return ql;
     };
     const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
-    constexpr int PRE = kQuadPre;
     QuadRegs<PRE, FT> pre;
     quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
-    // ---- per-cell set-up (wave 0), fraction table, f0 block and first chunk -> LDS ----------------------------------------
-    const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
-    // fraction table: the reference's fp32 coordinate of every tap column / row of every cell (local_correlation.py:55
-    // adds window offsets in normalised units, grid_sample un-normalises).  lane = cell, wave = tap index: no division.
-    bool tab_bad = false;
-    constexpr int NTAB = (2 * D + kWaves - 1) / kWaves;
-#pragma unroll
-    for (int n = 0; n < NTAB; ++n) {
-        const int a = wave + n * kWaves;   // scalar
-        if (a < 2 * D) {
-            const bool isy = a >= D;
-            const int k = isy ? a - D : a;
-            const float lin = isy ? gfn::linspace_step_at(ylo, yhi, p.win_ystep, D, k) : gfn::linspace_step_at(xlo, xhi, p.win_xstep, D, k);
-            const float pix = unnorm((isy ? my_ny : my_nx) + lin, isy ? H : W);
-            const float fl = floorf(pix);
-            const int origin = isy ? c.Y0 : c.X0;
-            // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
-            tab_bad |= (origin != kFar) & !(fl == (float)(origin + k));
-            tab[lane * TS + a] = pix - fl;
-        }
-    }
-    if (wave == 0) {
+    // ---- per-cell set-up (wave 0), f0 block and first chunk -> LDS ------------------------------------------------------------
+    if (wave == 0) {  // scalar
+        const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
         cellX0[lane] = c.X0;
         cellY0[lane] = c.Y0;
         cellNx[lane] = my_ok ? my_nx : 0.f;
@@ -517,10 +509,18 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const unsigned long long slow_mask = __ballot(c.flag == kCellSlow);
         if (lane == 0) hdr[4] = __popcll(slow_mask);
     }
-    {
-        const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
+    if (f0_lane) {
 #pragma unroll
-        for (int k = 0; k < NF0; ++k) f0s[fcell * CS + wave + k * kWaves] = fok ? f0v[k] : 0.f;
+        for (int l = 0; l < NF0L; ++l) {
+            const int ch = wave + (4 * l + fk) * kWaves;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fc = 4 * fq + e;
+                const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
+                const bool fok = (row0 + fr < G) & (col0 + fc < G);
+                f0s[fcell * CS + ch] = fok ? f0q[l][e] : 0.f;
+            }
+        }
     }
     STAMP(2);
     quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
@@ -528,7 +528,31 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     STAMP(3);
     __syncthreads();
     STAMP(4);
-    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    {
+        // fraction table: the reference's fp32 coordinate of every tap column / row of every cell (local_correlation.py:55 adds
+        // window offsets in normalised units, grid_sample un-normalises).  lane = cell, wave = tap index: no division.  Read by the
+        // epilogue, barriers from here.
+        const float cnx = cellNx[lane], cny = cellNy[lane];
+        const int cX0 = cellX0[lane], cY0 = cellY0[lane];
+        bool tab_bad = false;
+        constexpr int NTAB = (2 * D + kWaves - 1) / kWaves;
+#pragma unroll
+        for (int n = 0; n < NTAB; ++n) {
+            const int a = wave + n * kWaves;   // scalar
+            if (a < 2 * D) {
+                const bool isy = a >= D;
+                const int k = isy ? a - D : a;
+                const float lin = isy ? gfn::linspace_step_at(ylo, yhi, p.win_ystep, D, k) : gfn::linspace_step_at(xlo, xhi, p.win_xstep, D, k);
+                const float pix = unnorm((isy ? cny : cnx) + lin, isy ? H : W);
+                const float fl = floorf(pix);
+                const int origin = isy ? cY0 : cX0;
+                // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
+                tab_bad |= (origin != kFar) & !(fl == (float)(origin + k));
+                tab[lane * TS + a] = pix - fl;
+            }
+        }
+        if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    }
 
     // ---- per-lane D-stage addressing ---------------------------------------------------------------------------------
     int g, s16;

@@ -74,7 +74,7 @@ struct Mm {
     static constexpr int kDbufBytes = (NC * DS * 4 + 127) & ~127;
     // NPASS == 1: the D buffer has LDS of its own, so that a block's accumulators leave as soon as its products are done (no
     // barrier, no live range); two-pass shapes (C = 64) keep them across the passes and alias the D buffer over the stage
-    static constexpr bool kDbufAlias = NPASS > 1;  // (the kernel keys its two code paths on NPASS)
+    static constexpr bool kDbufAlias = NPASS > 1 || R >= 5;  // (large windows: the D buffer alone is 70-90 KB)
     static constexpr int kStage = (kMmLds - kCellBytes - kTabBytes - kF0Bytes - (kDbufAlias ? 0 : kDbufBytes)) & ~127;
     static constexpr int kCap = kStage / SLOT - 32;             // positions that fit (a block may read 31 slots past the region's end)
     static_assert(kDbufBytes <= kStage, "the D buffer may alias the stage");
@@ -291,15 +291,11 @@ __device__ __forceinline__ void mm_fetch(const LcParams &p, MmFetch<R, C, FT> &f
         for (int k = 0; k < F::NF0; ++k) f.f0v[k] = buf_ld(f0r, fgoff, (unsigned)(fw * F::NF0 + k) * GG4);
     }
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, t.b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
-    if (t.interior) {
+    // one code path for interior and border tiles (out-of-image pixels are masked at the commit): a block-uniform branch around the
+    // loads turns the loaded registers into phi nodes, which the compiler parks in scratch
 #pragma unroll
-        for (int n = 0; n < kMmPre; ++n) f.ml.it[n] = mm_item<R, C, false, FT>(t.u, H, W, wave, lane, n);
-        mm_issue<false, FT>(f.pre, f1r, 0u, H, W, t.u, t.ipw, f.ml);
-    } else {
-#pragma unroll
-        for (int n = 0; n < kMmPre; ++n) f.ml.it[n] = mm_item<R, C, true, FT>(t.u, H, W, wave, lane, n);
-        mm_issue<true, FT>(f.pre, f1r, 0u, H, W, t.u, t.ipw, f.ml);
-    }
+    for (int n = 0; n < kMmPre; ++n) f.ml.it[n] = mm_item<R, C, true, FT>(t.u, H, W, wave, lane, n);
+    mm_issue<true, FT>(f.pre, f1r, 0u, H, W, t.u, t.ipw, f.ml);
 }
 
 template <int R, int C, typename FT>
@@ -398,13 +394,8 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                 }
             }
             STAMP(1);
-            if (ct.interior) {
-                mm_commit<R, C, false, FT>(smem, cur.pre, ipw, cur.ml);
-                mm_rest<R, C, false, FT>(smem, f1r, 0u, H, W, u, ipw, wave, lane);
-            } else {
-                mm_commit<R, C, true, FT>(smem, cur.pre, ipw, cur.ml);
-                mm_rest<R, C, true, FT>(smem, f1r, 0u, H, W, u, ipw, wave, lane);
-            }
+            mm_commit<R, C, true, FT>(smem, cur.pre, ipw, cur.ml);
+            mm_rest<R, C, true, FT>(smem, f1r, 0u, H, W, u, ipw, wave, lane);
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -443,8 +434,9 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                 nb = any ? min((by1 - by0 - rp + 1) >> 1, NBW) : 0;  // the plan guarantees <= NBW
             }
 
-            // ---- the next tile's loads go out now and stay in flight until the top of the next iteration -------------------------
-            if (has_next) mm_fetch<R, C, FT>(p, nxt, wid_next, pl_next, lane, wave);
+            // ---- the next tile's loads go out now and stay in flight until the top of the next iteration (shapes that keep their
+            // accumulators across passes: behind the accumulators, see below) ------------------------------------------------------
+            if (!M::kDbufAlias && has_next) mm_fetch<R, C, FT>(p, nxt, wid_next, pl_next, lane, wave);
             STAMP(4);
 
             // ---- products --------------------------------------------------------------------------------------------------------
@@ -481,7 +473,7 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                 const unsigned base = s * (unsigned)M::SLOT + ((lpiece ^ mm_swz<KC>(s)) << 4);
                 return *reinterpret_cast<const bf16x8_t *>(smem + (base ^ (unsigned)(sc * 32)));
             };
-            if constexpr (NPASS == 1) {
+            if constexpr (!M::kDbufAlias) {
                 // Two blocks at a time, complete over the channels, filed in the D buffer at once: 8 accumulator registers alive (16
                 // with the next pair's products under way) instead of 4 NBW.  Rows past the group's box repeat its last row into
                 // values nobody files (they fail every cell's row test).
@@ -522,20 +514,26 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                     const bool more = ps + 1 < NPASS;
                     const unsigned next_off = (unsigned)((ps + 1) * KC) * (unsigned)(H * W) * (unsigned)sizeof(FT);
                     MmRegs<FT> pre2;
-                    if (more) {  // next pass's loads: in flight across the products
-                        if (ct.interior) mm_issue<false, FT>(pre2, f1r, next_off, H, W, u, ipw, cur.ml);
-                        else mm_issue<true, FT>(pre2, f1r, next_off, H, W, u, ipw, cur.ml);
-                    }
+                    if (more) mm_issue<true, FT>(pre2, f1r, next_off, H, W, u, ipw, cur.ml);  // next pass's loads: in flight across the products
 #pragma unroll
                     for (int sc = 0; sc < NSUB; ++sc) {
                         const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t *>(f0b + b_addr + (ps * NSUB + sc) * 64);
                         const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t *>(f0b + b_addr + (ps * NSUB + sc) * 64 + 32);
+                        // the operand addresses are re-derived per sub-chunk (5 instructions a block): kept in common across the
+                        // sub-chunks and passes they cost NBW registers beside 4 NBW accumulators and 32 of loads in flight
+                        unsigned slot_sc = slot0;
+                        asm volatile("" : "+v"(slot_sc));
+                        auto a_op = [&](int i) {
+                            const unsigned s = slot_sc + (unsigned)i * sstep;
+                            const unsigned base = s * (unsigned)M::SLOT + ((lpiece ^ mm_swz<KC>(s)) << 4);
+                            return *reinterpret_cast<const bf16x8_t *>(smem + (base ^ (unsigned)(sc * 32)));
+                        };
 #pragma unroll
                         for (int i0 = 0; i0 < NBW; i0 += 2) {
                             if (i0 < nb) {  // scalar
                                 bf16x8_t a[2];
 #pragma unroll
-                                for (int j = 0; j < 2; ++j) a[j] = a_operand(min(i0 + j, nb - 1), sc);
+                                for (int j = 0; j < 2; ++j) a[j] = a_op(min(i0 + j, nb - 1));
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) acc[i0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b1, acc[i0 + j], 0, 0, 0);
 #pragma unroll
@@ -545,13 +543,8 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                     }
                     if (more) {
                         __syncthreads();  // everyone is done reading this pass's pixels
-                        if (ct.interior) {
-                            mm_commit<R, C, false, FT>(smem, pre2, ipw, cur.ml);
-                            mm_rest<R, C, false, FT>(smem, f1r, next_off, H, W, u, ipw, wave, lane);
-                        } else {
-                            mm_commit<R, C, true, FT>(smem, pre2, ipw, cur.ml);
-                            mm_rest<R, C, true, FT>(smem, f1r, next_off, H, W, u, ipw, wave, lane);
-                        }
+                        mm_commit<R, C, true, FT>(smem, pre2, ipw, cur.ml);
+                        mm_rest<R, C, true, FT>(smem, f1r, next_off, H, W, u, ipw, wave, lane);
                         __syncthreads();
                     }
                 }
@@ -560,6 +553,9 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
 #pragma unroll
                 for (int i = 0; i < NBW; ++i)
                     if ((i & ~1) < nb) extract(i, acc[i]);
+                // the next tile's loads go out once the accumulators are gone (their 4 NBW registers and the two passes' load
+                // registers leave no room earlier) and fly under the epilogue -- (2 r + 1)^2 stores per cell at these radii
+                if (has_next) mm_fetch<R, C, FT>(p, nxt, wid_next, pl_next, lane, wave);
             }
             STAMP(6);
             __syncthreads();

@@ -95,6 +95,17 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype, pair
         assert_close(np.where(amb_w[..., 0], cert_o, host(cert)[b:b + 1]), cert_o, 1e-4, f"pair {b}: certainty")
 
 
+def _bench_flows(B, G, S, seed):
+    """Flows like the bench's: true warps of 15 % corner-perturbation homographies (both directions) + 0.25-px noise."""
+    from gfnet_amd import _synthetic as synthetic
+
+    gen = torch.Generator().manual_seed(seed)
+    H = synthetic.random_homographies(B // 2, S, gen)
+    f = torch.cat((synthetic.warp_grid(H, G, S, "cpu"), synthetic.warp_grid(np.linalg.inv(H), G, S, "cpu"))).permute(0, 3, 1, 2)
+    f = f + torch.randn(B, 2, G, G, generator=gen) * (0.5 / S)
+    return f.contiguous().numpy().astype(np.float32)
+
+
 @pytest.mark.parametrize("c,hs,G,r,S", [(32, 112, 64, 4, 448), (16, 224, 128, 2, 448), (32, 168, 96, 4, 672)])
 def test_full_batch_local_correlation_vs_oracle(c, hs, G, r, S):
     """configs[1] at its real batch (64 directions: grid size, XCD remap, plan / halves / second-launch lists all differ
