@@ -838,7 +838,7 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
 
 // shapes whose default path is the matrix-core kernel (local_corr_mm.h)
 bool mm_shape(int C, int H, int W, int G, int r, int f16) {
-    const bool kmm = r >= 5 ? r <= 7 : (GFN_MM_DEFAULT != 0 && (r == 3 || r == 4));
+    const bool kmm = GFN_MM_DEFAULT != 0 && r >= 3 && r <= 7;  // == Lean<r>::kMM
     const long K = (long)(2 * r + 1) * (2 * r + 1);
     return kmm && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
            (long)C * G * G < (1L << 30);
