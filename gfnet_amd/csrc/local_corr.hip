@@ -832,8 +832,18 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 // 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
 bool lean_shape(int C, int H, int W, int G, int r, int f16) {
     const long K = (long)(2 * r + 1) * (2 * r + 1);
-    return r >= 1 && r <= 4 && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
-           (long)C * G * G < (1L << 30);
+    if (!(r >= 1 && r <= 7 && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
+          (long)C * G * G < (1L << 30)))
+        return false;
+    if (r >= 5) {
+        // Large windows: the 4 x 16-cell tile's region must fit the stage as a whole at the maps' nominal cell spacing (r = 7 on
+        // 32 x 32 / 48 x 48 maps: 20 x 36 positions of 819).  Where it would be staged in halves on every tile (r = 6 at spacing
+        // 1.75: 21 x 44) the round-1 kernel with its 2 x 16-cell tiles is faster (85 vs 113 us for 64 directions).
+        const double sx = (double)W / G, sy = (double)H / G;
+        const double pw = 2 * r + 2;
+        return (3 * sy + pw + 1) * (15 * sx + pw + 4) <= 0.95 * 819;
+    }
+    return true;
 }
 
 // shapes whose default path is the matrix-core kernel (local_corr_mm.h)
@@ -919,10 +929,46 @@ int launch_mm(const LcParams &p0, hipStream_t stream) {
     return gfn::check_launch("local_corr_irregular_kernel");
 }
 
+// the lean path (local_corr_lean.h): plan (unless the refiner-input launch wrote it), the tile kernel, and for r <= 2 the separate
+// second launch (r >= 3: the tile kernel's first workgroups are the second launch)
+template <int R, typename FT>
+int launch_lean_path(const LcParams &p0, hipStream_t stream) {
+    LcParams p = p0;
+    lean_window_params<R>(p);
+    constexpr int NC = 64;
+    const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
+    if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
+    const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) +
+                        (size_t)NC * ((Lean<R>::kF0Chunk ? kChunk : p.C) + 4) * 4;
+    if (lds2 > kMaxLds) return -1000;
+    if (!p.planned) {
+        hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
+        if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
+    }
+    switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
+        case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
+        case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
+        default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
+    }
+    if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
+    if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
+    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
+                       (size_t)NC * (p.C + 4) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, 2, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kMaxLds);
+    const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
+    hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
+    return gfn::check_launch("local_corr_irregular_kernel");
+}
+
 template <int R, int ROUNDS, typename FT>
 int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     if constexpr (Lean<R>::kMM) {
         if (lean && p0.mm) return launch_mm<R, FT>(p0, stream);
+    }
+    if (lean) {
+        const int rc = launch_lean_path<R, FT>(p0, stream);
+        if (rc != -1000) return rc;  // -1000: the lean kernel's LDS does not take this shape -> round-1 kernel below
     }
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;
@@ -948,26 +994,8 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    if constexpr (ROUNDS == 2) {
-        if (lean) {
-            const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) + (size_t)NC * (p.C + 4) * 4;
-            if (!p.planned) {
-                hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
-                if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
-            }
-            switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-                case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
-                case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
-                default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
-            }
-            if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
-            if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
-        }
-    }
-    if (!(lean && ROUNDS == 2)) {
-        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
-        if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
-    }
+    hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
+    if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
     const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
     hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
     return gfn::check_launch("local_corr_irregular_kernel");

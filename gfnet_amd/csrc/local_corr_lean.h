@@ -46,7 +46,11 @@ __device__ __forceinline__ int cell_col(int c) { return (c & 7) + ((c >> 5) << 3
 // 40 KB three workgroups fit a CU
 template <int R>
 struct Lean {
-    static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : 64 * 1024;  // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU
+    // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU.  r = 7: the D buffer that aliases the stage (64 cells x 257
+    // floats) needs 65 792 bytes; with the f0 block staged chunk by chunk (kF0Chunk) the total stays at 80 160
+    static constexpr int kDbuf = (64 * ((2 * R + 2) * (2 * R + 2) + 1) * 4 + 15) & ~15;
+    static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : (kDbuf > 64 * 1024 ? kDbuf : 64 * 1024);
+    static constexpr bool kF0Chunk = R >= 5;  // 64-channel maps: 16 channels of the f0 block in LDS at a time (5 KB instead of 17)
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
@@ -400,7 +404,7 @@ struct DivPW {
     static constexpr int S = 12;
     static constexpr int M = ((1 << S) + PW - 1) / PW;
     static constexpr bool exact() {
-        for (int v = 0; v < 128; ++v)
+        for (int v = 0; v < 272; ++v)
             if (((v * M) >> S) != v / PW) return false;
         return true;
     }
@@ -422,7 +426,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
     constexpr int D = 2 * R + 1, K = D * D;
     constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
-    constexpr int CS = C + 4;
+    constexpr bool F0CH = Lean<R>::kF0Chunk;       // the f0 block goes through LDS one 16-channel chunk at a time
+    constexpr int CS = (F0CH ? kChunk : C) + 4;
     static_assert(NC * DS * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
 
     float4 *s4 = reinterpret_cast<float4 *>(smem);
@@ -466,21 +471,37 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
     // the tile's f0 block: wave w takes channels w, w + 8, ...; one 16-byte load per lane = four consecutive cells of a grid row of
     // one of them (lane >> 4 = which channel, lane & 15 = tile row and column quad): C / 32 loads per wave instead of C / 8
-    constexpr int NF0 = C / kWaves;              // channels per wave
-    constexpr int NF0L = (NF0 + 3) / 4;          // loads per wave
+    constexpr int NF0 = (F0CH ? kChunk : C) / kWaves;   // channels per wave (of the chunk, when staged chunk by chunk)
+    constexpr int NF0L = (NF0 + 3) / 4;                 // loads per wave
     f32x4 f0q[NF0L];
-    const int fk = lane >> 4, fr = (lane & 15) >> 2, fq = lane & 3;
+    const int fk = lane >> 4, fr = (lane & 15) >> 2, fqd = lane & 3;
     const bool f0_lane = fk < (NF0 < 4 ? NF0 : 4);
-    {
-        const bool in = f0_lane & (row0 + fr < G) & (col0 + 4 * fq < G);
-        const rsrc_t f0r = make_rsrc(p.f0 + (size_t)b * p.f0_bs, (unsigned)C * GG4);
+    const rsrc_t f0r = make_rsrc(p.f0 + (size_t)b * p.f0_bs, (unsigned)C * GG4);
+    auto f0_issue = [&](int c0) {   // c0: first channel of the chunk (0 when the whole block is staged at once)
+        const bool in = f0_lane & (row0 + fr < G) & (col0 + 4 * fqd < G);
 #pragma unroll
         for (int l = 0; l < NF0L; ++l) {
-            const int ch = wave + (4 * l + fk) * kWaves;
-            const unsigned fgoff = in ? (unsigned)((row0 + fr) * G + col0 + 4 * fq) * 4u + (unsigned)ch * GG4 : 0u;
+            const int ch = c0 + wave + (4 * l + fk) * kWaves;
+            const unsigned fgoff = in ? (unsigned)((row0 + fr) * G + col0 + 4 * fqd) * 4u + (unsigned)ch * GG4 : 0u;
             f0q[l] = buf_ld4(f0r, fgoff, 0u);
         }
-    }
+    };
+    auto f0_commit = [&]() {
+        if (f0_lane) {
+#pragma unroll
+            for (int l = 0; l < NF0L; ++l) {
+                const int ch = wave + (4 * l + fk) * kWaves;   // channel inside what f0s holds
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fc = 4 * fqd + e;
+                    const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
+                    const bool fok = (row0 + fr < G) & (col0 + fc < G);
+                    f0s[fcell * CS + ch] = fok ? f0q[l][e] : 0.f;
+                }
+            }
+        }
+    };
+    f0_issue(0);
     // items of a chunk in flight per wave.  r <= 2: the 40 KB stage holds 512 positions = 512 lane items of a 16-channel chunk = one
     // item per lane, so a second register set only ever repeated the first item's loads -- half of the kernel's vector-memory
     // instructions, each a full trip through the texture-address path
@@ -509,19 +530,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const unsigned long long slow_mask = __ballot(c.flag == kCellSlow);
         if (lane == 0) hdr[4] = __popcll(slow_mask);
     }
-    if (f0_lane) {
-#pragma unroll
-        for (int l = 0; l < NF0L; ++l) {
-            const int ch = wave + (4 * l + fk) * kWaves;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int fc = 4 * fq + e;
-                const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
-                const bool fok = (row0 + fr < G) & (col0 + fc < G);
-                f0s[fcell * CS + ch] = fok ? f0q[l][e] : 0.f;
-            }
-        }
-    }
+    f0_commit();
     STAMP(2);
     quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
     quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
@@ -599,13 +608,16 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);  // next step's loads: in flight across this D-stage
+        if (more) {  // next step's loads: in flight across this D-stage
+            quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
+            if (F0CH) f0_issue(nch * kChunk);
+        }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
             float f[kChunk];
             {
-                const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + c0);
+                const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + (F0CH ? 0 : c0));
                 const float4 a0 = fq[0], a1 = fq[1], a2 = fq[2], a3 = fq[3];
                 f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
                 f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w; f[12] = a3.x; f[13] = a3.y; f[14] = a3.z; f[15] = a3.w;
@@ -633,6 +645,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             STAMP(7);
             quad_commit<PRE, CHECK, FT>(s4, pre, H, W, un, wave, lane, qn, 0);
             quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
+            if (F0CH) f0_commit();
             __syncthreads();
             STAMP(8);
         }
