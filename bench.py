@@ -89,6 +89,21 @@ def solve_parity(scene, good, Hl, n):
     return float(np.mean(vs_oracle)), float(np.mean(vs_truth))
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: RCCL prints a version banner on stdout when its first communicator
+    comes up, and the driver wants exactly ONE line there, the JSON."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +122,9 @@ def parse_args():
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="take the self-launch path (parent starts the rank processes, relays rank 0's line) also for --gpus 1: the "
+                         "single child then runs inside a torch.distributed world of one, so barrier and time reduction go through RCCL")
     ap.add_argument("--dry-run", action="store_true",
                     help="no kernels: every rank contributes made-up 3x3 matrices, so that rank start-up, the H all-gather and the JSON relay "
                          "can be exercised without a GPU (tests/test_parallel_cpu.py, with --backend gloo)")
@@ -132,7 +150,8 @@ def self_launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    for line in out.splitlines():  # the JSON line on stdout, anything else a library wrote there on stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
     return max((abs(rc) for rc in rcs), default=0)
 
@@ -233,7 +252,7 @@ def secondary_workload(key, conv_stack, dev, rank, steps):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_launcher) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     if args.dry_run:
         sys.exit(dry_run(args))
@@ -245,13 +264,23 @@ def main():
     from gfnet_amd import ops, parallel
     from gfnet_amd._synthetic import FLOW_NOISE_PX, WORKLOADS, Scene, side_of
 
-    rank, world, local = parallel.init_from_env(backend=args.backend)
+    with stdout_to_stderr():
+        rank, world, local = parallel.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or "
                          "unset WORLD_SIZE and let bench.py start the ranks itself")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
     torch.cuda.set_device(local)
+    # a world of one under the self-launcher (--force-launcher): still a process group, so that the barrier and the reduction of
+    # the step time below run through RCCL on the box the driver has (prove the relay with RCCL loaded)
+    group_of_one = world == 1 and bool(os.environ.get("GFN_BENCH_CHILD")) and not dist.is_initialized()
+    if group_of_one:
+        with stdout_to_stderr():
+            dist.init_process_group(backend=args.backend, rank=0, world_size=1)
+    if world > 1 or group_of_one:
+        with stdout_to_stderr():  # the communicator (and RCCL's banner) comes up with the first collective
+            dist.barrier()
     dev = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
     B = args.pairs_per_gpu or wl["pairs"]
@@ -269,8 +298,10 @@ def main():
         Hl = torch.cat([o[0] for o in outs])
         return parallel.gather_homographies(Hl), outs
 
+    in_group = world > 1 or group_of_one
+
     def sync():
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -279,7 +310,7 @@ def main():
         for i in range(args.warmup):
             step(i)
         sync()
-        if world > 1:
+        if in_group:
             n_ranks_seen = dist.get_world_size()  # after an RCCL barrier: the ranks the collective really had
         if args.breakdown and rank == 0:
             from gfnet_amd.estimation import estimate_homographies
@@ -346,7 +377,7 @@ def main():
     others = None
     if args.workload == "448b32" and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
         others = {k: secondary_workload(k, "off", dev, rank, 5) for k in ("672b16", "pyr-fp16")}
-    if world > 1:
+    if in_group:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -378,7 +409,8 @@ def main():
     out = {
         "metric": "image pairs/sec at 448x448 (post-backbone hot path: correlation -> flow -> sampling -> homography)"
                   if args.workload == "448b32" else f"image pairs/sec, workload {args.workload} (post-backbone hot path)",
-        "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps,
+        "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
+        "collective_backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if in_group else None, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["label"], "workload_key": args.workload, "pairs_per_gpu": pairs_per_step,
@@ -428,7 +460,7 @@ def main():
         out["other_workloads"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
 

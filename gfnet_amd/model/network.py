@@ -180,7 +180,8 @@ class ConvRefiner(nn.Module):
         if variant is None:
             if self.conv_precision not in ("fp32", "fp16", "amp"):
                 raise ValueError("conv_precision must be 'fp32', 'fp16' (1x1 operands) or 'amp' (fp16 operands and maps)")
-            if self.conv_precision == "amp" and d.shape[-1] % 4 == 0 and d.shape[-1] == d.shape[-2]:
+            # (a one-block stack has no map between blocks: fp32 in, fp32 out is the fp16-operand kernel's job -- ADVICE r2)
+            if self.conv_precision == "amp" and d.shape[-1] % 4 == 0 and d.shape[-1] == d.shape[-2] and len(fold) > 1:
                 return self._conv_stack_half(d, fold, out_conv)
             variant = 2 if self.conv_precision in ("fp16", "amp") else 0
         x, bufs = d, [None, None]

@@ -490,7 +490,8 @@ def conv_block(x, packed, M, out=None, variant=0, t_scratch=None):
 def conv_block_half(x, packed, C, M, out=None, out_half=True):
     """conv_block on fp16 maps (the reference's amp=True class, model/network.py:560-562): x is (B,C,G,G) float32 or a
     half map (B,ceil(C/2),G,G,2) float16 (channel pairs side by side); returns a half map (B,ceil(M/2),G,G,2), or (B,M,G,G)
-    float32 with out_half=False.  Depthwise/BatchNorm/accumulation fp32, 1x1 operands fp16."""
+    float32 with out_half=False.  The autocast class: depthwise 5x5 and 1x1 operands fp16 (the input halo, the folded taps, the
+    ReLU output and the 1x1 weights are rounded), every accumulation, BatchNorm and ReLU fp32 (include/gfnet_hip.h)."""
     dev = require_gpu(x, packed)
     x_half = x.dtype == torch.float16
     if x_half:

@@ -80,13 +80,17 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
                        float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                        int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
-/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4, the
- * round-1 tile kernel above), 1 = force the general per-tap kernel, 2 = the round-1 tile kernel for every radius (the
- * bit-exact cross-check of the lean path); + 8: the plan of this call is already in scratch (gfn_refiner_input_plan_fwd_dt).  Same
- * arguments otherwise.
+/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4 and for
+ * r >= 5 where a 4 x 16-cell tile's windows fit the LDS stage as a whole -- r = 7 on GFNet's maps --, otherwise the round-1 tile
+ * kernel above; builds with -DGFN_MM_DEFAULT=1 send r >= 3 to the matrix-core kernel of csrc/local_corr_mm.h instead: split-bf16
+ * products, NOT bit-identical to the fp32 FMA kernels, within 1e-4 * max(1, |ref|)), 1 = force the general per-tap kernel, 2 = the
+ * round-1 tile kernel for every radius (the bit-exact cross-check of the lean path), 4 = the lean tile path with its fp32 FMA
+ * D-stage whatever the build's default (bit-identical to 2); + 8: the plan of this call is already in scratch
+ * (gfn_refiner_input_plan_fwd_dt; only with 0).  Same arguments otherwise.
  * Scratch header (ints): [0] tiles left to the second launch, [1..2] its queue counters, [3] last call's [0], [4] cells redone
  * per tap, [5] last call's [4], [6] tiles staged as two halves (sampled), [7] last call's [6]; [0..2], [4], [6] are zero
- * between calls. */
+ * between calls.  [4]..[7] are informational and approximate: the r >= 3 kernels publish and reset them from inside the launch
+ * while other workgroups may still be adding, so a handful of flagged cells can be attributed to the next call. */
 int gfn_local_corr_fwd_ex(const float *f0, int64_t f0_bs, const float *f1, const float *f1_second, const float *flow,
                           float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                           int win_w, int variant, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
@@ -322,7 +326,10 @@ int gfn_pointwise_conv_fwd(const float *w, const float *bias, const float *t, fl
 
 /* gfn_conv_block_half_fwd: the same block with fp16 maps in HBM -- the reference's amp=True refiners, where every map
  *   between two blocks is a float16 tensor (torch.autocast around block1 + hidden_blocks, model/network.py:560-562).
- *   Arithmetic as gfn_conv_block_fwd variant 2 (depthwise, BatchNorm and accumulation fp32, 1x1 operands fp16); a map of
+ *   Arithmetic = the autocast class: the depthwise 5x5 runs on the matrix core too (v_mfma_f32_16x16x32_f16: the input halo --
+ *   also a first block's fp32 concat -- and the folded taps rounded to fp16, fp32 accumulation), BatchNorm + ReLU fp32, ReLU output
+ *   and 1x1 weights fp16, fp32 accumulation; builds with -DGFN_CONV_VALU_DW keep the depthwise in fp32 as gfn_conv_block_fwd
+ *   variant 2 does.  A map of
  *   dtype GFN_F16 is (B, ceil(C/2), G, G) of half2: channels 2p and 2p+1 of a cell side by side, the odd channel past C zero
  *   (the kernel writes it so).  x_dtype / y_dtype: GFN_F32 (B, C, G, G) floats or GFN_F16; at least one of them GFN_F16 (a
  *   stack's first block reads the fp32 concat, its last one writes fp32).  G must be a multiple of 4. */
