@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256) void local_corr_bwd_f0_kernel(LcParams p, cons
     }
 }
 
+#include "local_corr_stage.h"
+
 // ---- fast tiled kernel -----------------------------------------------------------------------
 // Stage traffic: wave-iteration wi covers channel group (wi & 3) of the 64 region pixels starting
 // at (wi >> 2) * 64: four coalesced row-segment loads (one per channel) and one 16-byte LDS write
@@ -487,10 +489,19 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     Region u;
     u.x0 = bbox[0]; u.y0 = bbox[1];
     u.w = max(bbox[2] - u.x0, 0); u.h = max(bbox[3] - u.y0, 0);
-    u.pitch = u.w + ((PW - u.w) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
+    // Round 3, r >= 5 (64-channel maps): the stage loads are 16-byte quads through a buffer descriptor (local_corr_stage.h) instead
+    // of 4-byte loads -- a 2 x 16-cell tile at r = 6 issued ~750 wave-level loads, the whole kernel's time in the CU's
+    // vector-memory issue path.  A row is then whole quads (the last one may hang over the region's right edge: its pixels land in
+    // pad slots nobody reads; past the tensor the descriptor returns zeros).  fp16 maps need even x0 and even rows (4-byte aligned
+    // 8-byte quads); odd-width fp16 maps keep the narrow loads.
+    constexpr bool kQuads = STAGED && R >= 5;
+    const bool quads = kQuads && (sizeof(FT) == 4 || (W & 1) == 0);  // fp32 maps: a compile-time constant (no branch around the loads)
+    if (quads && sizeof(FT) == 2 && (u.x0 & 1)) { u.x0 -= 1; u.w += 1; }
+    const int w4 = quads ? ((u.w + 3) & ~3) : u.w;
+    u.pitch = w4 + ((PW - w4) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
     // a region that only fits without that padding is staged unpadded: some bank conflicts in the D-stage cost far less
     // than the second launch
-    if (STAGED && (long)u.pitch * u.h > kCapSlots && (long)u.w * u.h <= kCapSlots) u.pitch = u.w;
+    if (STAGED && (long)u.pitch * u.h > kCapSlots && (long)w4 * u.h <= kCapSlots) u.pitch = w4;
     if (STAGED && (long)u.pitch * u.h > kCapSlots) {
         // strong magnification / rotation / scattered flow: the windows do not fit the stage
         if (!SECOND) {
@@ -511,7 +522,20 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     constexpr int PRE0 = R <= 2 ? 4 : 6;  // the first chunk is requested before the D-stage registers exist: more of it in flight at
                                           // once (r <= 2 regions need 3.5 iterations; unused ones still cost their index math)
     StageRegs<PRE0, FT> pre0;
-    if (STAGED && !ABL(p, 1)) stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
+    // the quad form (r >= 5): the region as a RowPlan, two items per lane in flight
+    RowPlan up;
+    up.x0 = u.x0; up.y0 = u.y0; up.w = u.w; up.h = u.h; up.pitch = u.pitch; up.nq = (u.w + 3) >> 2;
+    up.nitems = ((up.h * up.nq + 15) / 16 + 7) & ~7;
+    QuadLane qlq;
+    QuadRegs<kQuadPre, FT> preq;
+    const rsrc_t f1r = make_rsrc(f1b, (unsigned)p.C * (unsigned)(H * W) * (unsigned)sizeof(FT));
+    if (quads) {
+#pragma unroll
+        for (int n = 0; n < kQuadPre; ++n) qlq.it[n] = quad_item<false, FT, kSlotV4, true>(up, H, W, wave, lane, n);
+        quad_issue<kQuadPre, false, FT, kSlotV4, true>(preq, f1r, 0u, H, W, up, wave, lane, qlq, 0);
+    } else if (STAGED && !ABL(p, 1)) {
+        stage_issue(pre0, f1b, H, W, u, wave, lane, 0);
+    }
 
     // fraction table: the reference's fp32 coordinate of every tap column / row of every cell
     // (local_correlation.py:55 adds window offsets in normalised units, grid_sample un-normalises)
@@ -574,7 +598,10 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     STAMP(3);
     // ---- main loop: 16 channels at a time ----------------------------------------------------
     const size_t cs = (size_t)G * G;
-    if (STAGED && !ABL(p, 1)) {
+    if (quads) {
+        quad_commit<kQuadPre, false, FT>(s4, preq, H, W, up, wave, lane, qlq, 0);
+        quad_rest<false, FT>(s4, f1r, 0u, H, W, up, wave, lane, qlq, kQuadPre);
+    } else if (STAGED && !ABL(p, 1)) {
         stage_commit(s4, pre0);
         stage_rest<2>(s4, f1b, H, W, u, wave, lane, PRE0);
     }
@@ -591,7 +618,9 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
 #pragma unroll
                 for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));
             // next chunk's loads: in flight across this chunk's D-stage
-            if (more && !ABL(p, 1)) stage_issue(pre, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, 0);
+            const unsigned next_off = (unsigned)(c0 + kChunk) * (unsigned)(H * W) * (unsigned)sizeof(FT);
+            if (more && quads) quad_issue<kQuadPre, false, FT, kSlotV4, true>(preq, f1r, next_off, H, W, up, wave, lane, qlq, 0);
+            else if (more && !ABL(p, 1)) stage_issue(pre, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, 0);
         }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -661,7 +690,11 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         STAMP(5 + (c0 != 0 ? 2 : 0));
         if (STAGED && more) {
             __syncthreads();  // everyone is done reading this chunk
-            if (!ABL(p, 1)) {
+            if (quads) {
+                const unsigned next_off = (unsigned)(c0 + kChunk) * (unsigned)(H * W) * (unsigned)sizeof(FT);
+                quad_commit<kQuadPre, false, FT>(s4, preq, H, W, up, wave, lane, qlq, 0);
+                quad_rest<false, FT>(s4, f1r, next_off, H, W, up, wave, lane, qlq, kQuadPre);
+            } else if (!ABL(p, 1)) {
                 stage_commit(s4, pre);
                 stage_rest<2>(s4, f1c + (size_t)kChunk * H * W, H, W, u, wave, lane, PRE);
             }
