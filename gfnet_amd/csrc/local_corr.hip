@@ -868,13 +868,18 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
     if (!(r >= 1 && r <= 7 && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
           (long)C * G * G < (1L << 30)))
         return false;
+    // Large windows (r >= 5): the lean tile kernel handles them (f0 block staged chunk by chunk, 65 792-byte stage at r = 7) and is on
+    // par with the round-1 kernel on smooth flows where the 4 x 16-cell tile's region fits the stage (r = 7 on 32 x 32 maps: 80.7 vs
+    // 79.5 us), slower where every tile would be staged in halves (r = 6 at spacing 1.75: 113 vs 79 us) and under the raw
+    // soft-argmax flows scale 16 sees in the bench (160 vs 110 + 44 us: its in-launch second-launch workers) -- the round-1 kernel
+    // with quad staging keeps them.  -DGFN_LEAN_R7=1 builds send r = 7 here.
     if (r >= 5) {
-        // Large windows: the 4 x 16-cell tile's region must fit the stage as a whole at the maps' nominal cell spacing (r = 7 on
-        // 32 x 32 / 48 x 48 maps: 20 x 36 positions of 819).  Where it would be staged in halves on every tile (r = 6 at spacing
-        // 1.75: 21 x 44) the round-1 kernel with its 2 x 16-cell tiles is faster (85 vs 113 us for 64 directions).
-        const double sx = (double)W / G, sy = (double)H / G;
-        const double pw = 2 * r + 2;
+#if defined(GFN_LEAN_R7) && GFN_LEAN_R7
+        const double sx = (double)W / G, sy = (double)H / G, pw = 2 * r + 2;
         return (3 * sy + pw + 1) * (15 * sx + pw + 4) <= 0.95 * 819;
+#else
+        return false;
+#endif
     }
     return true;
 }

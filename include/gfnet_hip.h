@@ -80,9 +80,8 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
                        float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                        int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
-/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4 and for
- * r >= 5 where a 4 x 16-cell tile's windows fit the LDS stage as a whole -- r = 7 on GFNet's maps --, otherwise the round-1 tile
- * kernel above; builds with -DGFN_MM_DEFAULT=1 send r >= 3 to the matrix-core kernel of csrc/local_corr_mm.h instead: split-bf16
+/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4, the round-1 tile
+ * kernel above for r >= 5; builds with -DGFN_MM_DEFAULT=1 send r >= 3 to the matrix-core kernel of csrc/local_corr_mm.h instead: split-bf16
  * products, NOT bit-identical to the fp32 FMA kernels, within 1e-4 * max(1, |ref|)), 1 = force the general per-tap kernel, 2 = the
  * round-1 tile kernel for every radius (the bit-exact cross-check of the lean path), 4 = the lean tile path with its fp32 FMA
  * D-stage whatever the build's default (bit-identical to 2); + 8: the plan of this call is already in scratch
