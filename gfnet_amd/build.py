@@ -66,6 +66,27 @@ def build_ablate(verbose=False):
     return out
 
 
+def build_mm(verbose=False):
+    """The parked matrix-core local-correlation kernel (csrc/local_corr_mm.h) as a library of its own, libgfnet_hip_mm.so:
+    local_corr.hip compiled with -DGFN_MM_DEFAULT=1, every other object shared with the product library.  Not the product path;
+    tests/test_local_corr_mm_gpu.py keeps its parity claim checkable."""
+    src = os.path.join(CSRC, "local_corr.hip")
+    obj = os.path.join(CSRC, "local_corr_mm.o")
+    out = os.path.join(CSRC, "libgfnet_hip_mm.so")
+    if _stale(obj, _deps(src)):
+        cmd = [HIPCC] + FLAGS + ["-DGFN_MM_DEFAULT=1", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    others = [s[:-4] + ".o" for s in sources() if not s.endswith("local_corr.hip")]
+    if _stale(out, [obj] + others):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, obj] + others
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force=False, verbose=False, extra=()):
     srcs = sources()
     if force:
@@ -87,6 +108,10 @@ def build(force=False, verbose=False, extra=()):
 if __name__ == "__main__":
     if "--ablate" in sys.argv:
         print(build_ablate(verbose=True))
+        sys.exit(0)
+    if "--mm" in sys.argv:
+        build(verbose=True)
+        print(build_mm(verbose=True))
         sys.exit(0)
     extra = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
     print(build(force="--force" in sys.argv, verbose=True, extra=extra))

@@ -886,9 +886,11 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
 
 // shapes whose default path is the matrix-core kernel (local_corr_mm.h)
 bool mm_shape(int C, int H, int W, int G, int r, int f16) {
-    const bool kmm = GFN_MM_DEFAULT != 0 && r >= 3 && r <= 7;  // == Lean<r>::kMM
+    const bool kmm = GFN_MM_DEFAULT != 0 && (r == 3 || r == 4);  // == Lean<r>::kMM (r = 6, 7 were measured slower still and spill)
     const long K = (long)(2 * r + 1) * (2 * r + 1);
-    return kmm && (C == 16 || C == 32 || C == 64) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
+    // (one channel count per radius is built: GFNet's r = 4 on 32-channel maps, and r = 3 on 16 for the tests -- every further
+    // instantiation of the persistent kernel costs ~40 s of compile time)
+    return kmm && C == (r == 4 ? 32 : 16) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
            (long)C * G * G < (1L << 30);
 }
 
@@ -950,11 +952,8 @@ int launch_mm(const LcParams &p0, hipStream_t stream) {
                                   kMmLds);                                                                                                 \
         hipLaunchKernelGGL((local_corr_mm1_kernel<R, CC, FT>), grid, dim3(kMmThreads), kMmLds, stream, p);                                 \
     } while (0)
-    switch (p.C) {
-        case 16: GFN_MM_LAUNCH(16); break;
-        case 32: GFN_MM_LAUNCH(32); break;
-        default: GFN_MM_LAUNCH(64); break;
-    }
+    if constexpr (R == 4) GFN_MM_LAUNCH(32);  // mm_shape: one channel count per radius
+    else GFN_MM_LAUNCH(16);
 #undef GFN_MM_LAUNCH
     if (int e = gfn::check_launch("local_corr_mm1_kernel")) return e;
     constexpr int NC = 64;
@@ -1004,9 +1003,16 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     if constexpr (Lean<R>::kMM) {
         if (lean && p0.mm) return launch_mm<R, FT>(p0, stream);
     }
-    if (lean) {
-        const int rc = launch_lean_path<R, FT>(p0, stream);
-        if (rc != -1000) return rc;  // -1000: the lean kernel's LDS does not take this shape -> round-1 kernel below
+#if defined(GFN_LEAN_R7) && GFN_LEAN_R7
+    constexpr bool kLeanBuilt = true;
+#else
+    constexpr bool kLeanBuilt = R <= 4;  // lean_shape() never takes r >= 5 in this build: do not instantiate those kernels
+#endif
+    if constexpr (kLeanBuilt) {
+        if (lean) {
+            const int rc = launch_lean_path<R, FT>(p0, stream);
+            if (rc != -1000) return rc;  // -1000: the lean kernel's LDS does not take this shape -> round-1 kernel below
+        }
     }
     LcParams p = p0;
     constexpr int NC = 32 * ROUNDS;

@@ -56,7 +56,7 @@ struct Lean {
     static constexpr int PW = 2 * R + 2;
     // R >= 5 (GFNet: r = 6, 7 on 64-channel maps, 196 / 256 products per cell and channel): the matrix-core kernel is the default
     // path; R = 3, 4 only in GFN_MM_DEFAULT builds (there the lean fp32 kernel, two workgroups per CU, is still faster)
-    static constexpr bool kMM = GFN_MM_DEFAULT && R >= 3;  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
+    static constexpr bool kMM = GFN_MM_DEFAULT && (R == 3 || R == 4);  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
