@@ -121,8 +121,12 @@ __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsig
         unsigned vo;
         if (k0 == 0 && n < kQuadPre) vo = (n == 0 || n < ipw) ? ql.it[n].voff : (OOR ? kOffRange : ql.it[0].voff);
         else vo = quad_item<CHECK, FT, UNIT, OOR>(u, H, W, wave, lane, max(min(k0 + n, ipw - 1), 0)).voff;
+        // a wave whose item n lies wholly past the region's last quad issues nothing for it (wave-uniform branch)
+        const bool real = !OOR || n == 0 || (wave + 8 * (k0 + n)) * 16 < u.h * u.nq;
+        if (real) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
+            for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
+        }
     }
 }
 
