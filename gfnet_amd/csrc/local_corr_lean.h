@@ -304,10 +304,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     // The tile kernels queue for the vector-memory pipe (a wave-load costs 30-40 cycles of the CU's texture-address path, and a
     // tile issued ~180 of them): every load that is not needed is gone.  lane = cell id (cells 0-31 left half, 32-63 right half);
     // only wave 0 reads the 64 flows and files the per-cell arrays; the fraction table is derived from those behind the barrier.
+#ifndef GFN_LEAN_FLOW_ALL
+#define GFN_LEAN_FLOW_ALL 0  // 1: every wave reads the flows and fills its share of the table under the stage loads (14 more loads per tile): measured level
+#endif
+    constexpr bool kFlowAll = GFN_LEAN_FLOW_ALL != 0;
     const int my_gi = row0 + cell_row(lane), my_gj = col0 + cell_col(lane);
     const bool my_ok = (my_gi < G) & (my_gj < G);
     float my_nx = 0.f, my_ny = 0.f;
-    if (wave == 0) {  // scalar
+    if (kFlowAll || wave == 0) {  // scalar
         const rsrc_t flr = make_rsrc(p.flow + (size_t)b * 2 * G * G, 2u * GG4);
         const unsigned fo = my_ok ? (unsigned)(my_gi * G + my_gj) * 4u : 0u;
         my_nx = buf_ld(flr, fo, 0u);
@@ -375,18 +379,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (lane == 0) hdr[4] = __popcll(slow_mask);
     }
     f0_commit();
-    STAMP(2);
-    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
-    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
-    {
+    auto fill_table = [&](float cnx, float cny, int cX0, int cY0) {
         // fraction table: the reference's fp32 coordinate of every tap column / row of every cell (local_correlation.py:55 adds
         // window offsets in normalised units, grid_sample un-normalises).  lane = cell, wave = tap index: no division.  Read by the
         // epilogue, barriers from here.
-        const float cnx = cellNx[lane], cny = cellNy[lane];
-        const int cX0 = cellX0[lane], cY0 = cellY0[lane];
         bool tab_bad = false;
         constexpr int NTAB = (2 * D + kWaves - 1) / kWaves;
 #pragma unroll
@@ -404,8 +400,21 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
                 tab[lane * TS + a] = pix - fl;
             }
         }
-        if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+        return tab_bad;
+    };
+    bool tab_bad = false;
+    if (kFlowAll) {  // every wave has the flows: its share of the table under the stage loads' latency
+        const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
+        tab_bad = fill_table(my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, c.X0, c.Y0);
     }
+    STAMP(2);
+    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
+    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
+    STAMP(3);
+    __syncthreads();
+    STAMP(4);
+    if (!kFlowAll) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
 
     // ---- per-lane D-stage addressing ---------------------------------------------------------------------------------
     int g, s16;
