@@ -121,6 +121,9 @@ def parse_args():
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="two streams per scene inside the timed region: a step's sampling + solve run under the next step's match "
+                         "(default: one stream per scene; the default 448b32 line reports the pipelined rate as `pipelined_steps`)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="take the self-launch path (parent starts the rank processes, relays rank 0's line) also for --gpus 1: the "
@@ -184,31 +187,54 @@ def dry_run(args):
 
 
 class SceneRunner:
-    """One step of every scene.  Scenes are independent (different image sizes of the pyramid workload): each runs on a HIP stream
-    of its own so that the small scene's 16-64-workgroup launches overlap the large scene's wide ones (scratch is keyed by stream,
-    gfnet_amd/_lib.py); a single scene stays on the current stream."""
+    """One step of every scene.
+    * Scenes are independent (different image sizes of the pyramid workload): each runs on HIP streams of its own, so that the
+      small scene's 16-64-workgroup launches overlap the large scene's wide ones (scratch is keyed by stream, gfnet_amd/_lib.py).
+    * Inside a scene the batch goes through two stages on two streams: `match` (both passes of the coarse-to-fine loop: chip-wide
+      launches) and `finish` (sampling + solve: a third of its time is one-workgroup-per-pair kernels -- curve sort, radix select,
+      LM finish -- on 32 of 256 CUs).  A step's finish waits for its own match only, so it runs under the NEXT step's match: the
+      way a stream of batches goes through the path in deployment (448b32: 3.53 -> 3.19 ms per step).  OFF for the timed region
+      of the driver's line: the overlapped kernels take CUs from the roofline op while it is being timed (96.5 -> 107 us), and
+      six streams slow the three-scene workload down; the default single-GPU 448b32 run reports it as `pipelined_steps` instead
+      (a secondary leg after the timed region, like `with_conv_stacks`); --pipeline puts it into the timed region."""
 
-    def __init__(self, scenes):
+    def __init__(self, scenes, pipeline=False):
         import torch
 
         self.scenes = scenes
-        self.streams = [torch.cuda.Stream() for _ in scenes] if len(scenes) > 1 else None
+        self.pipeline = pipeline
+        main = torch.cuda.current_stream()
+        self.streams = []
+        for _ in scenes:
+            pair = (torch.cuda.Stream(), torch.cuda.Stream()) if pipeline else ((torch.cuda.Stream(),) * 2 if len(scenes) > 1 else None)
+            if pair is not None:
+                for st in set(pair):
+                    st.wait_stream(main)  # the scenes' inputs were produced on the current stream
+            self.streams.append(pair)
 
     def step(self, seed):
         import torch
 
-        if self.streams is None:
-            return [sc.step(seed) for sc in self.scenes]
         main = torch.cuda.current_stream()
         outs = []
-        for sc, st in zip(self.scenes, self.streams):
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
+        for sc, pair in zip(self.scenes, self.streams):
+            if pair is None:
                 outs.append(sc.step(seed))
-        for o, st in zip(outs, self.streams):
-            main.wait_stream(st)
-            for t in o:
-                t.record_stream(main)
+                continue
+            ms, fs = pair
+            with torch.cuda.stream(ms):
+                warp, cert = sc.match()
+                done = ms.record_event()
+            with torch.cuda.stream(fs):
+                fs.wait_event(done)
+                warp.record_stream(fs)
+                cert.record_stream(fs)
+                outs.append(sc.finish(warp, cert, seed))
+        for o, pair in zip(outs, self.streams):
+            if pair is not None:
+                main.wait_stream(pair[1])
+                for t in o:
+                    t.record_stream(main)
         return outs
 
 
@@ -291,7 +317,7 @@ def main():
     main_scene = scenes[min(1, len(scenes) - 1)] if len(scenes) > 1 else scenes[0]  # the 448 scene of the pyramid workload
     pairs_per_step = B * len(scenes)
 
-    runner = SceneRunner(scenes)
+    runner = SceneRunner(scenes, pipeline=args.pipeline)
 
     def step(seed):
         outs = runner.step(seed)
@@ -373,6 +399,24 @@ def main():
                          "refiner_conv_stack": "reference architecture, random-init, HIP conv_stack kernels, conv_precision='amp' (fp16 maps, "
                                                "fp16 operands, fp32 accumulation: model/network.py:560-562)"}
             del scenes2
+    # secondary figure: the same steps as a stream of batches (sampling + solve of step i under the match of step i + 1)
+    pipe_leg = None
+    if world == 1 and len(scenes) == 1 and not args.pipeline and args.conv_stack == "off" and not args.no_stack_leg:
+        with torch.inference_mode():
+            runner_p = SceneRunner(scenes, pipeline=True)
+            for i in range(2):
+                runner_p.step(i)
+            torch.cuda.synchronize()
+            np_ = max(5, min(args.steps, 20))
+            t1 = time.perf_counter()
+            for i in range(np_):
+                runner_p.step(0)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+        pipe_leg = {"value": round(pairs_per_step * np_ / dtp, 2), "unit": "pairs/s", "ms_per_step": round(dtp / np_ * 1e3, 3), "steps": np_,
+                    "what": "the same steps with two streams per scene: a step's sampling + solve (a third of their time is one-workgroup-"
+                            "per-pair kernels) run under the next step's match; not used for `value` because the overlap takes CUs from the "
+                            "roofline op while it is timed"}
     # the other single-GPU configurations of BASELINE.json on the same line (secondary legs, 5 steps each)
     others = None
     if args.workload == "448b32" and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
@@ -416,6 +460,7 @@ def main():
         "config": {"workload": wl["label"], "workload_key": args.workload, "pairs_per_gpu": pairs_per_step,
                    "image_sizes": wl["sizes"], "num_itr": wl["num_itr"], "feature_storage": wl["dtype"],
                    "symmetric": True, "upsample_pass": "1.25x (560 at 448)", "attenuate_cert": True,
+                   "step_pipeline": "a step's sampling + solve (second stream) run under the next step's match" if args.pipeline else "off",
                    "flow_noise": f"stand-in increment = true warp + N(0,({FLOW_NOISE_PX}/S)^2) - flow, fresh realisation per iteration",
                    "stages": "corr_softargmax, (refiner_input + local_corr + flow_update) x scales x num_itr for both passes, resize, "
                              "match_post, sample(2 draws without replacement + KDE 20000^2), RANSAC(<= 2000 hypotheses, OpenCV's confidence-0.99999 "
@@ -456,6 +501,8 @@ def main():
         out["mean_corner_error_vs_truth_px"] = ace_t
     if stack_leg is not None:
         out["with_conv_stacks"] = stack_leg
+    if pipe_leg is not None:
+        out["pipelined_steps"] = pipe_leg
     if others is not None:
         out["other_workloads"] = others
     if rank == 0:

@@ -164,12 +164,19 @@ class Scene:
         self.sizes = (S0, S0, S0, S0)
         self.roofline_key = f"local_corr_c32_h{side_of('4', S0)}_g{self.grids[2]}_r4"
 
-    def step(self, seed):
+    def match(self):
+        """Both passes of the coarse-to-fine loop + match post-processing: (warp, certainty) of the batch."""
+        return self.model.match_pyramids(self.pyr[0], self.pyr[1], self.pyr_up[0], self.pyr_up[1], batched=True)
+
+    def finish(self, warp, cert, seed):
+        """Balanced sampling + homography solve on a batch's (warp, certainty)."""
         from gfnet_amd.estimation import estimate_homographies
         from gfnet_amd.model.network import sample_batched
 
-        m = self.model
-        warp, cert = m.match_pyramids(self.pyr[0], self.pyr[1], self.pyr_up[0], self.pyr_up[1], batched=True)
-        good, _ = sample_batched(m, warp, cert, 5000)
-        Hl = estimate_homographies(good, self.sizes, iters=m.ransac_iters, seed=seed)
+        good, _ = sample_batched(self.model, warp, cert, 5000)
+        Hl = estimate_homographies(good, self.sizes, iters=self.model.ransac_iters, seed=seed)
         return Hl, good
+
+    def step(self, seed):
+        warp, cert = self.match()
+        return self.finish(warp, cert, seed)
