@@ -23,17 +23,22 @@
 // conflict in the f0 filing hid the rest (118 us against the lean kernel's 99).
 // This version gives the CU to ONE 16-wave workgroup:
 //   * all channels of a position are staged at once (up to 32: 128-byte slots; 64-channel maps take two passes), so a block is
-//     complete after 2 x KC/16 instructions and at most NBW = 10 blocks (40 registers) are alive per wave -- four waves serve a
-//     group (column tile x row parity);
+//     complete after 2 x KC/16 instructions and is filed in the D buffer at once: 8-16 accumulator registers alive per wave (two
+//     passes: 4 NBW = 40, kept across them) -- four waves serve a group (column tile x row parity);
 //   * slots carry no padding: the eight 16-byte pieces of a slot (hi/lo x channel octet) are XOR-swizzled with bits of the slot
 //     index, which makes both the A-operand read (16 consecutive slots, one piece pair) and the staging writes conflict-free;
-//     ~1100 positions fit (819 before), so the "halves" mode is gone;
+//     ~800 positions fit beside the D buffer (single-pass shapes), so the "halves" mode is gone;
 //   * the D buffer (rows of PW + 6 floats: three guard columns either side, so a lane's four consecutive positions need one range
 //     test) has LDS of its own (~100 KB stage + 41 KB D buffer at r = 4): accumulators leave right behind their products;
 //   * the workgroup is PERSISTENT: it walks tiles bid, bid + gridDim, ... of an XCD-contiguous order, and the next tile's loads
 //     (flow, f0 block, f1 quads: ~40 registers) are in flight under the current tile's products and epilogue -- with one
 //     workgroup per CU nothing else would cover the L2 round trip and the ~12 B/clk at which a CU's staging loads drain
 //     (measured one tile per workgroup: 13 k cycles per tile of which 7 k waiting for the loads).
+//
+// Outcome (profiles/r03_local_corr_mm.md): every phase is short (products 1.8-2.5 k cycles against the fp32 D-stage's 2 x 2.8-4.5 k),
+// but one workgroup per CU runs them in lockstep and the issue of a tile's ~190 staging loads alone takes 5-6 k cycles: 123 us
+// for the scale-4 op against the lean fp32 kernel's 91-98.  PARKED: built only with -DGFN_MM_DEFAULT=1 (libgfnet_hip_mm.so, r = 4
+// on 32-channel and r = 3 on 16-channel maps), kept parity-green by tests/test_local_corr_mm_gpu.py.
 //
 // Numerics class: NOT bit-identical to the fp32 FMA kernels (variant 4: the round-2 lean kernel, variant 2: round 1), which stay
 // as cross-checks.
