@@ -71,6 +71,7 @@ struct LcParams {
     long todo_ints;
     int planned;                      // lean path: the plan is already in scratch (gfn_refiner_input_plan_fwd_dt wrote it)
     int mm;                           // the plan is for / the tiles go to the matrix-core kernel (local_corr_mm.h) where Lean<R>::kMM
+    int mq;                           // r >= 5: the first launch is the matrix-core tile kernel (local_corr_mq.h)
     int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 
 #include "local_corr_lean.h"
 #include "local_corr_mm.h"
+#include "local_corr_mq.h"
 
 // shapes the lean tile path takes (it keeps at most 8 channels of the f0 block per wave in registers, addresses planes with
 // 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
@@ -892,6 +894,14 @@ bool mm_shape(int C, int H, int W, int G, int r, int f16) {
     // instantiation of the persistent kernel costs ~40 s of compile time)
     return kmm && C == (r == 4 ? 32 : 16) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
            (long)C * G * G < (1L << 30);
+}
+
+// large windows on 64-channel maps: the matrix-core tile kernel of local_corr_mq.h is the first launch (byte offsets into the maps and
+// the kOffRange marker share 31 bits)
+bool mq_shape(int C, int H, int W, int G, int r, int f16) {
+    const long K = (long)(2 * r + 1) * (2 * r + 1);
+    return GFN_MQ != 0 && r >= 5 && r <= 7 && C == 64 && !(f16 && (W & 1)) && (long)C * H * W * (f16 ? 2 : 4) < 0x7FFFFFF0L &&
+           K * G * G * 4 < 0x7FFFFFF0L && (long)C * G * G * 4 < 0x7FFFFFF0L;
 }
 
 // scratch layout of the lean path: header and tile list (ints), then the plan, 32-byte aligned
@@ -1038,8 +1048,21 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
-    if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
+    bool mq = false;
+    if constexpr (R >= 5 && GFN_MQ != 0) {
+        static_assert(ROUNDS == 1, "the matrix-core kernel's tiles are the round-1 kernel's 2 x 16 cells: they share the second launch");
+        mq = p.mq != 0;
+        if (mq) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mq_kernel<R, 64, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kMqLds);
+            hipLaunchKernelGGL((local_corr_mq_kernel<R, 64, FT>), dim3(total), dim3(kThreads), kMqLds, stream, p);
+            if (int e = gfn::check_launch("local_corr_mq_kernel")) return e;
+        }
+    }
+    if (!mq) {
+        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
+        if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
+    }
     const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
     hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
     return gfn::check_launch("local_corr_irregular_kernel");
@@ -1111,6 +1134,7 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
     if (variant == 4) variant = 0;
     const bool tiled = variant == 0 && flow && !grid_based && win_h == H && win_w == W;
     p.mm = (want_mm && tiled && mm_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
+    p.mq = (want_mm && tiled && mq_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
     bool lean = tiled && (p.mm || lean_shape(C, H, W, G, r, p.f16));
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
     p.planned = planned ? 1 : 0;

@@ -123,11 +123,12 @@ struct MmItem {
                      // 18-21: pixels inside the image (CHECK); 22: the lane has a quad; 23: its row lies inside the image (CHECK)
 };
 
-template <int R, int C, bool CHECK, typename FT>
+// M = the kernel's traits (Mm<R, C> here, Mq<R, C> in local_corr_mq.h): NSUB, KC, SLOT, NPIECE; NW = waves of the workgroup
+// OOR: a lane without a quad gets an offset past the descriptor's range (the load returns zeros without touching memory)
+template <typename M, int NW, bool CHECK, typename FT, bool OOR = false>
 __device__ __forceinline__ MmItem mm_item(const MmRegion &u, int H, int W, int wave, int lane, int k) {
-    typedef Mm<R, C> M;
     constexpr unsigned ES = sizeof(FT);
-    const int it = wave + kMmWaves * k;
+    const int it = wave + NW * k;
     const int qg = it / M::NSUB, sc = it % M::NSUB;  // scalar
     const int cg = sc * 4 + ((lane >> 2) & 3);         // channel quad of the pass
     const int L = qg * 16 + ((lane & 3) | ((lane >> 4) << 2));
@@ -145,6 +146,7 @@ __device__ __forceinline__ MmItem mm_item(const MmRegion &u, int H, int W, int w
     MmItem o;
     const int px = CHECK ? (row_in ? gy : 0) * W + max(x, 0) : row * W + x;
     o.voff = (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES;
+    if (OOR && !have) o.voff = kOffRange;
     const unsigned s0 = (unsigned)(row * u.pitch + 4 * q);           // slot of pixel 0: a multiple of 4
     const unsigned phys = (unsigned)(cg >> 1) ^ mm_swz<M::KC>(s0);   // hi piece of pixels 0-1
     const unsigned a8 = s0 * (M::SLOT / 8) + phys * 2u + (unsigned)(cg & 1);
@@ -161,7 +163,7 @@ struct MmRegs {
     typename QuadRaw<FT>::type a[kMmPre][4];
 };
 
-template <bool CHECK, typename FT>
+template <bool CHECK, typename FT, bool OOR = false>
 __device__ __forceinline__ void mm_issue(MmRegs<FT> &r, rsrc_t f1r, unsigned pass_off, int H, int W, const MmRegion &u, int ipw, const MmLane &ml) {
     constexpr unsigned ES = sizeof(FT);
     const unsigned plane4 = (unsigned)(H * W) * ES;
@@ -170,16 +172,15 @@ __device__ __forceinline__ void mm_issue(MmRegs<FT> &r, rsrc_t f1r, unsigned pas
     for (int n = 0; n < kMmPre; ++n) {
         // no branch around the loads (a wave without a second item repeats its first one: L1 hits): behind a branch the loaded
         // registers become phi nodes and the compiler waits for them at the merge -- nothing stays in flight
-        const unsigned vo = (n == 0 || n < ipw) ? ml.it[n].voff : ml.it[0].voff;
+        const unsigned vo = (n == 0 || n < ipw) ? ml.it[n].voff : (OOR ? kOffRange : ml.it[0].voff);
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
     }
 }
 
 // one item's 4 pixels x 4 channels -> bf16 hi / lo pieces
-template <int R, int C, bool CHECK, typename FT>
+template <typename M, bool CHECK, typename FT>
 __device__ __forceinline__ void mm_commit_one(unsigned char *stage, const typename QuadRaw<FT>::type (&a)[4], unsigned meta) {
-    typedef Mm<R, C> M;
     u32x2_t *s8 = reinterpret_cast<u32x2_t *>(stage);
     const unsigned a01 = meta & 0x3FFFFu;                         // hi piece half of pixels 0-1, in units of 8 bytes
     const unsigned a23 = M::KC == 32 ? a01 ^ 2u : a01;            // pixels 2-3: slot + 2 flips bit 0 of the KC = 32 swizzle
@@ -200,27 +201,27 @@ __device__ __forceinline__ void mm_commit_one(unsigned char *stage, const typena
     }
 }
 
-template <int R, int C, bool CHECK, typename FT>
+template <typename M, bool CHECK, typename FT>
 __device__ __forceinline__ void mm_commit(unsigned char *stage, const MmRegs<FT> &r, int ipw, const MmLane &ml) {
 #pragma unroll
     for (int n = 0; n < kMmPre; ++n) {
         const unsigned meta = ml.it[n].meta;
-        if ((n < ipw) & ((meta >> 22) & 1u)) mm_commit_one<R, C, CHECK, FT>(stage, r.a[n], meta);
+        if ((n < ipw) & ((meta >> 22) & 1u)) mm_commit_one<M, CHECK, FT>(stage, r.a[n], meta);
     }
 }
 
 // items beyond the kMmPre register-held ones (regions of more than 512 / NSUB quads)
-template <int R, int C, bool CHECK, typename FT>
+template <typename M, int NW, bool CHECK, typename FT>
 __device__ __forceinline__ void mm_rest(unsigned char *stage, rsrc_t f1r, unsigned pass_off, int H, int W, const MmRegion &u, int ipw, int wave, int lane) {
     constexpr unsigned ES = sizeof(FT);
     const unsigned plane4 = (unsigned)(H * W) * ES;
     const unsigned so = pass_off + (CHECK ? 0u : (unsigned)(u.y0 * W) * ES);
     for (int k = kMmPre; k < ipw; ++k) {
-        const MmItem it = mm_item<R, C, CHECK, FT>(u, H, W, wave, lane, k);
+        const MmItem it = mm_item<M, NW, CHECK, FT>(u, H, W, wave, lane, k);
         typename QuadRaw<FT>::type a[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = QuadRaw<FT>::load(f1r, it.voff, so + (unsigned)j * plane4);
-        if ((it.meta >> 22) & 1u) mm_commit_one<R, C, CHECK, FT>(stage, a, it.meta);
+        if ((it.meta >> 22) & 1u) mm_commit_one<M, CHECK, FT>(stage, a, it.meta);
     }
 }
 
@@ -299,7 +300,7 @@ __device__ __forceinline__ void mm_fetch(const LcParams &p, MmFetch<R, C, FT> &f
     // one code path for interior and border tiles (out-of-image pixels are masked at the commit): a block-uniform branch around the
     // loads turns the loaded registers into phi nodes, which the compiler parks in scratch
 #pragma unroll
-    for (int n = 0; n < kMmPre; ++n) f.ml.it[n] = mm_item<R, C, true, FT>(t.u, H, W, wave, lane, n);
+    for (int n = 0; n < kMmPre; ++n) f.ml.it[n] = mm_item<Mm<R, C>, kMmWaves, true, FT>(t.u, H, W, wave, lane, n);
     mm_issue<true, FT>(f.pre, f1r, 0u, H, W, t.u, t.ipw, f.ml);
 }
 
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                 }
             }
             STAMP(1);
-            mm_commit<R, C, true, FT>(smem, cur.pre, ipw, cur.ml);
-            mm_rest<R, C, true, FT>(smem, f1r, 0u, H, W, u, ipw, wave, lane);
+            mm_commit<M, true, FT>(smem, cur.pre, ipw, cur.ml);
+            mm_rest<M, kMmWaves, true, FT>(smem, f1r, 0u, H, W, u, ipw, wave, lane);
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -548,8 +549,8 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
                     }
                     if (more) {
                         __syncthreads();  // everyone is done reading this pass's pixels
-                        mm_commit<R, C, true, FT>(smem, pre2, ipw, cur.ml);
-                        mm_rest<R, C, true, FT>(smem, f1r, next_off, H, W, u, ipw, wave, lane);
+                        mm_commit<M, true, FT>(smem, pre2, ipw, cur.ml);
+                        mm_rest<M, kMmWaves, true, FT>(smem, f1r, next_off, H, W, u, ipw, wave, lane);
                         __syncthreads();
                     }
                 }

@@ -143,6 +143,49 @@ def test_lean_tile_kernel_is_bit_identical_to_round1_kernel(c, hs, G, r, flow_ki
         assert_close(default, oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
 
 
+def _flows_of_kind(flow_kind, B, G, seed):
+    if flow_kind == "homography":
+        return synth.homography_flow(B, G, seed)
+    if flow_kind == "zoom":
+        return synth.homography_flow(B, G, seed + 1, scale=1.7)
+    if flow_kind == "random":
+        return 1.2 * synth.lattice_uniform((B, 2, G, G), seed + 2)
+    if flow_kind == "noisy":  # smooth flow + a few pixels of noise: groups of 2 x 8 cells whose windows spread past the accumulators
+        return synth.homography_flow(B, G, seed + 5) + np.float32(0.18) * synth.lattice_uniform((B, 2, G, G), seed + 6)
+    if flow_kind == "border":  # shifted so that a band of windows hangs over / leaves the image on every side
+        flow = synth.homography_flow(B, G, seed + 3, scale=1.02)
+        flow[0, 0] += np.float32(0.35); flow[1, 0] -= np.float32(0.4); flow[2, 1] += np.float32(0.3); flow[3, 1] -= np.float32(0.45)
+        return flow
+    lin = (np.arange(G, dtype=np.float64) * 2 + 1) / G - 1  # rotations by 10..40 degrees about the centre
+    gy, gx = np.meshgrid(lin, lin, indexing="ij")
+    flow = np.empty((B, 2, G, G), np.float32)
+    for b in range(B):
+        a = np.deg2rad(10.0 * (b + 1))
+        flow[b, 0] = (np.cos(a) * gx - np.sin(a) * gy) * 0.9
+        flow[b, 1] = (np.sin(a) * gx + np.cos(a) * gy) * 0.9
+    return flow + np.float32(0.002) * synth.lattice_uniform((B, 2, G, G), seed + 4)
+
+
+@pytest.mark.parametrize("hs,G,r", [(32, 32, 7), (56, 32, 6), (70, 40, 6), (48, 48, 7), (45, 27, 5), (37, 21, 6)])
+@pytest.mark.parametrize("flow_kind", ["homography", "zoom", "random", "noisy", "border", "rot"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_large_windows_on_the_matrix_core_vs_fp32_kernel_and_oracle(hs, G, r, flow_kind, f16):
+    """r >= 5 on 64-channel maps: the default path multiplies on the matrix core (csrc/local_corr_mq.h: split-bf16 operands, windows
+    clipped to the image, tiles that do not fit its accumulators handed to the round-1 routine inside the launch or to the second
+    launch).  Every route against the round-1 fp32 FMA kernel (variant 2) and the oracle, fp32 and fp16 maps (odd map sides keep
+    fp16 maps on the round-1 kernel), grids that are not multiples of the tile."""
+    B, c = 4, 64
+    f0 = synth.lattice_normalish((B, c, G, G), 331 + r)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 332 + r)
+    if f16:
+        f1 = (f1 * np.float32(1.37)).astype(np.float16)
+    flow = _flows_of_kind(flow_kind, B, G, 340).astype(np.float32)
+    default = run(f0, f1, flow, r, G)
+    fp32_kernel = run(f0, f1, flow, r, G, _variant=2)
+    assert_close(default, fp32_kernel, TOL, f"matrix core vs fp32 FMA kernel, {flow_kind}")
+    assert_close(default, oracle.local_correlation((B, c, hs, hs), f0, f1.astype(np.float32), r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
+
+
 def test_ragged_sizes_and_rect_maps():
     # G not a multiple of the tile, rectangular f1, batch of 3
     B, c, h, w, G, r = 3, 16, 37, 53, 21, 3
