@@ -16,6 +16,12 @@
 //   * no plan launch: the workgroup derives its region from the 32 flows itself (wave 0; the other waves' f0 loads cover the
 //     round trip); a tile whose windows do not fit the groups' accumulators runs the round-1 routine (fp32 FMAs) in this workgroup,
 //     which leaves what does not fit its stage either to the second launch (2 x 8-cell sub-tiles).
+// Where a tile's ~27 k cycles go (tools/stamp_local_corr.py 64 64 70 40 6, GFN_ABLATE build): 4.5-5 k until the region is known (kernel
+// arguments, the flows' round trip to memory, ~400 instructions of one wave), 6 k until chunk 0 is filed, 4 x 2.8 k per chunk -- of which
+// the products are 0.3-0.6 k and the rest the next chunk's loads arriving and being split -- 4 k to file the accumulators and store.
+// The matrix core took the D-stage off the critical path; what is left is the latency of dependent loads with two workgroups per CU to
+// overlap it.  Tried without effect: the flows through the scalar cache (s_load_dwordx16 + v_writelane) and s_setprio for the set-up
+// wave (the wait is the memory round trip, not queueing or issue slots); skipping empty staging items by a branch.
 // Numerics: the class of local_corr_mm.h (products exact in fp32 up to 2^-17 relative per term, fp32 accumulation; fp16 maps split
 // exactly), not bit-identical to the fp32 FMA kernels.  -DGFN_MQ=0 builds keep r >= 5 on the round-1 kernel.
 
