@@ -254,7 +254,7 @@ def secondary_workload(key, conv_stack, dev, rank, steps):
     main_scene = scenes[min(1, len(scenes) - 1)]
     runner = SceneRunner(scenes)
     with torch.inference_mode():
-        for i in range(2):
+        for i in range(4):  # (the three-scene workload needs more than two steps to settle: allocator, stream pools)
             runner.step(i)
         torch.cuda.synchronize()
         ops.kernel_events = {main_scene.roofline_key: []}
@@ -420,7 +420,7 @@ def main():
     # the other single-GPU configurations of BASELINE.json on the same line (secondary legs, 5 steps each)
     others = None
     if args.workload == "448b32" and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
-        others = {k: secondary_workload(k, "off", dev, rank, 5) for k in ("672b16", "pyr-fp16")}
+        others = {k: secondary_workload(k, "off", dev, rank, 8) for k in ("672b16", "pyr-fp16")}
     if in_group:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

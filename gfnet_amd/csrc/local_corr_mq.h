@@ -47,6 +47,8 @@ struct Mq {
     static constexpr int kStage = (kMqLds - kCellBytes - kTabBytes - kF0Bytes) & ~127;
     static constexpr int kCap = kStage / SLOT - 32;             // positions that fit (a block may read 31 slots past the region's end)
     static_assert(kDbufBytes <= kStage, "the D buffer aliases the stage");
+    // what process_tile<R, 1, true, kTileW, false> lays out when this kernel hands it a tile: stage + cell arrays + f0 block [32][C + 4]
+    static_assert(kStageBytes + ((32 * 20 + 32 + 15) & ~15) + 32 * (C + 4) * 4 <= kMqLds, "the round-1 routine must fit this kernel's LDS");
     static_assert(C % 16 == 0 && C == 64, "built for 64-channel maps (8 waves x 8 channels of the f0 block)");
 };
 

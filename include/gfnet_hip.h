@@ -80,11 +80,12 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
                        float *out, int64_t out_bs, int B, int C, int G, int H, int W, int r, int grid_based, int win_h,
                        int win_w, void *scratch, int64_t scratch_bytes, gfn_stream_t stream);
 
-/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4, the round-1 tile
- * kernel above for r >= 5; builds with -DGFN_MM_DEFAULT=1 send r >= 3 to the matrix-core kernel of csrc/local_corr_mm.h instead: split-bf16
- * products, NOT bit-identical to the fp32 FMA kernels, within 1e-4 * max(1, |ref|)), 1 = force the general per-tap kernel, 2 = the
- * round-1 tile kernel for every radius (the bit-exact cross-check of the lean path), 4 = the lean tile path with its fp32 FMA
- * D-stage whatever the build's default (bit-identical to 2); + 8: the plan of this call is already in scratch
+/* Variant selector for experiments/tests: 0 = auto (as above: the lean tile path of csrc/local_corr_lean.h for r <= 4; for r >= 5 on
+ * 64-channel maps the matrix-core tile kernel of csrc/local_corr_mq.h -- split-bf16 products with fp32 accumulation, NOT bit-identical to
+ * the fp32 FMA kernels, within 1e-4 * max(1, |ref|) -- and the round-1 tile kernel above for other channel counts; builds with
+ * -DGFN_MM_DEFAULT=1 also send r = 3, 4 to a matrix-core kernel, csrc/local_corr_mm.h), 1 = force the general per-tap kernel, 2 = the
+ * round-1 fp32 tile kernel for every radius (the cross-check of the other paths), 4 = fp32 FMA arithmetic whatever the radius: the lean
+ * tile path for r <= 4, the round-1 kernel for r >= 5 (bit-identical to 2); + 8: the plan of this call is already in scratch
  * (gfn_refiner_input_plan_fwd_dt; only with 0).  Same arguments otherwise.
  * Scratch header (ints): [0] tiles left to the second launch, [1..2] its queue counters, [3] last call's [0], [4] cells redone
  * per tap, [5] last call's [4], [6] tiles staged as two halves (sampled), [7] last call's [6]; [0..2], [4], [6] are zero
