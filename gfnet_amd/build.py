@@ -67,7 +67,8 @@ def build_ablate(verbose=False):
 
 
 def build_mm(verbose=False):
-    """The parked matrix-core local-correlation kernel (csrc/local_corr_mm.h) as a library of its own, libgfnet_hip_mm.so:
+    """The parked r = 3 / 4 matrix-core local-correlation kernel (csrc/local_corr_mw.h: four waves per workgroup, a wave per group;
+    -DGFN_MM_DEFAULT=2 would build the persistent kernel of csrc/local_corr_mm.h instead) as a library of its own, libgfnet_hip_mm.so:
     local_corr.hip compiled with -DGFN_MM_DEFAULT=1, every other object shared with the product library.  Not the product path;
     tests/test_local_corr_mm_gpu.py keeps its parity claim checkable."""
     src = os.path.join(CSRC, "local_corr.hip")

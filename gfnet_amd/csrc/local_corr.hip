@@ -862,6 +862,9 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 #include "local_corr_lean.h"
 #include "local_corr_mm.h"
 #include "local_corr_mq.h"
+#if GFN_MM_DEFAULT == 1
+#include "local_corr_mw.h"
+#endif
 
 // shapes the lean tile path takes (it keeps at most 8 channels of the f0 block per wave in registers, addresses planes with
 // 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
@@ -954,6 +957,20 @@ int launch_mm(const LcParams &p0, hipStream_t stream) {
         hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
         if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
     }
+#if GFN_MM_DEFAULT == 1
+    // the four-wave kernel of local_corr_mw.h: one workgroup per tile
+#define GFN_MW_LAUNCH(CC)                                                                                                                  \
+    do {                                                                                                                                   \
+        constexpr int lds_mw = Mw<R, CC>::kLds;                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mw_kernel<R, CC, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  lds_mw);                                                                                                 \
+        hipLaunchKernelGGL((local_corr_mw_kernel<R, CC, FT>), dim3(total), dim3(kMwThreads), lds_mw, stream, p);                           \
+    } while (0)
+    if constexpr (R == 4) GFN_MW_LAUNCH(32);
+    else GFN_MW_LAUNCH(16);
+#undef GFN_MW_LAUNCH
+    if (int e = gfn::check_launch("local_corr_mw_kernel")) return e;
+#else
     const unsigned cus = (unsigned)device_cu_count();
     const dim3 grid(total < cus ? total : cus);
 #define GFN_MM_LAUNCH(CC)                                                                                                                  \
@@ -966,6 +983,7 @@ int launch_mm(const LcParams &p0, hipStream_t stream) {
     else GFN_MM_LAUNCH(16);
 #undef GFN_MM_LAUNCH
     if (int e = gfn::check_launch("local_corr_mm1_kernel")) return e;
+#endif
     constexpr int NC = 64;
     const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
                        (size_t)NC * (p.C + 4) * 4;

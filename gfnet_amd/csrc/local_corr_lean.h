@@ -23,6 +23,7 @@
 //   * tile = two 4 x 8-cell halves (cells 0-31 / 32-63), the epilogue still stores 64-byte row segments;
 //   * fraction table: lane = cell, wave = tap index (no division); stores use scalar plane offsets.
 
+constexpr int kMwRows = 16;  // local_corr_mw.h (GFN_MM_DEFAULT == 1): a group's box is at most kMwRows rows high
 constexpr int kMmNBW = 10;  // local_corr_mm.h: accumulator blocks per wave of the matrix-core kernel (a group's box: <= 2 kMmNBW rows)
 template <int R> __device__ __forceinline__ bool mm_region_fits_rt(int w, int h, int C);  // local_corr_mm.h
 
@@ -159,7 +160,7 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 gy0[k] = __builtin_amdgcn_readlane(ry0, l15);
                 gx1[k] = -__builtin_amdgcn_readlane(rx1, l15);
                 gy1[k] = -__builtin_amdgcn_readlane(ry1, l15);
-                if (Lean<R>::kMM && p.mm && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= 2 * kMmNBW);
+                if (Lean<R>::kMM && p.mm && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= (GFN_MM_DEFAULT == 1 ? kMwRows : 2 * kMmNBW));
             }
             hx0[h] = min(gx0[0], gx0[1]); hy0[h] = min(gy0[0], gy0[1]);
             hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
@@ -305,7 +306,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     // tile issued ~180 of them): every load that is not needed is gone.  lane = cell id (cells 0-31 left half, 32-63 right half);
     // only wave 0 reads the 64 flows and files the per-cell arrays; the fraction table is derived from those behind the barrier.
 #ifndef GFN_LEAN_FLOW_ALL
-#define GFN_LEAN_FLOW_ALL 0  // 1: every wave reads the flows and fills its share of the table under the stage loads (14 more loads per tile): measured level
+#define GFN_LEAN_FLOW_ALL 0  // 1: every wave reads the flows (14 more loads per tile) and does its table share and patch addressing under the stage loads; 0: wave 0 only, both behind the barrier.  Measured level (r = 4: 98.1 / 148.1 vs 99.0 / 150.1 us): with two workgroups per CU the tile kernels are bound by the total of their vector instructions, not by where in the tile they sit
 #endif
     constexpr bool kFlowAll = GFN_LEAN_FLOW_ALL != 0;
     const int my_gi = row0 + cell_row(lane), my_gj = col0 + cell_col(lane);
@@ -403,35 +404,17 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         return tab_bad;
     };
     bool tab_bad = false;
-    if (kFlowAll) {  // every wave has the flows: its share of the table under the stage loads' latency
-        const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
-        tab_bad = fill_table(my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, c.X0, c.Y0);
-    }
-    STAMP(2);
-    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
-    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
-    if (!kFlowAll) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
-    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
-
-    // ---- per-lane D-stage addressing ---------------------------------------------------------------------------------
+    // ---- per-lane D-stage addressing: the float4 index of every (round, pass) patch position of the lane's cell ----------------------
     int g, s16;
     lane_group(lane, g, s16);
     const int cr = wave * 4 + g;  // cell inside a half (0..31)
     unsigned apk[ROUNDS][(NP + 1) / 2];
-    float acc[ROUNDS][NP];
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int cell = rd * 32 + cr;
-        const int X0 = cellX0[cell], Y0 = cellY0[cell];
+    auto addressing = [&](int rd, int X0, int Y0) {
         const RowPlan &u = (HALVES && rd == 1) ? uB : uA;
         // cells without a patch (off the grid, flagged, empty) read slot 0 onwards: valid memory, result unused
         const int base = X0 != kFar ? (Y0 - u.y0) * u.pitch + (X0 - u.x0) : 0;
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
-            acc[rd][t] = 0.f;
             const int pp = s16 + 16 * t;
             const int yy = DivPW<PW>::div(pp), xx = pp - yy * PW;
             int slot = base + yy * u.pitch + xx;
@@ -442,7 +425,34 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             else
                 apk[rd][t >> 1] = a;
         }
+    };
+    if (kFlowAll) {
+        // every wave has the 64 flows (lane = cell id): its share of the fraction table AND its lanes' patch addresses (the origins
+        // of the lane's two cells come from the lanes that hold them) are worked out under the stage loads' latency instead of
+        // behind the barrier, where they were ~3 k of a tile's 22 k cycles at r = 4 with nothing in flight
+        const CellBox c = cell_box<PW>(my_ok, my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, xlo, ylo, W, H);
+        tab_bad = fill_table(my_ok ? my_nx : 0.f, my_ok ? my_ny : 0.f, c.X0, c.Y0);
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) addressing(rd, __shfl(c.X0, rd * 32 + cr), __shfl(c.Y0, rd * 32 + cr));
     }
+    STAMP(2);
+    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
+    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
+    STAMP(3);
+    __syncthreads();
+    STAMP(4);
+    if (!kFlowAll) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+
+    if (!kFlowAll) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) addressing(rd, cellX0[rd * 32 + cr], cellY0[rd * 32 + cr]);
+    }
+    float acc[ROUNDS][NP];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+        for (int t = 0; t < NP; ++t) acc[rd][t] = 0.f;
     STAMP(5);
 
     // ---- main loop: 16 channels at a time (per half when the tile is staged in halves) ------------------------------------

@@ -86,6 +86,25 @@ struct Mm {
     static_assert((kStage / 8) < (1 << 18), "slot addresses are packed in 18 bits");
 };
 
+// the four-wave shape of local_corr_mw.h (a wave per group: <= kMwRows rows x two column tiles of accumulators)
+template <int R, int C>
+struct Mw {
+    static constexpr int KC = 16, NCH = C / 16, NSUB = 1, NPIECE = 4, SLOT = 64;
+    static constexpr int PW = 2 * R + 2, D = 2 * R + 1, K = D * D, TS = 2 * D + 1;
+    static constexpr int NC = 64, NW = 4;
+    static constexpr int RP = PW + 6;
+    static constexpr int DS = ((PW * RP + 31) & ~31) + 5;
+    static constexpr int NBW = 2 * kMwRows;
+    static constexpr int kCellBytes = (NC * 20 + 96 + 16 + 15) & ~15;   // five per-cell arrays, 24 header ints, a 4-float dump
+    static constexpr int kTabBytes = (NC * TS * 4 + 15) & ~15;
+    static constexpr int kF0Cell = NCH * 64 + 16;
+    static constexpr int kF0Bytes = NC * kF0Cell;
+    static constexpr int kDbufBytes = NC * DS * 4;
+    static constexpr int kLds = 80 * 1024;
+    static constexpr int kStage = (kLds - kCellBytes - kTabBytes - kF0Bytes) & ~127;
+    static constexpr int kCap = kStage / SLOT - 32;
+};
+
 // swizzle of a slot's 16-byte pieces: piece p of slot s lives at physical piece p ^ mm_swz<KC>(s).  KC = 32 (8 pieces, slot stride
 // 32 dwords): (s >> 1) & 7 -- 16 consecutive slots reading one piece pair (p, p ^ 1) in the hardware's b128 lane groups
 // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} touch 16 different 4-bank groups.  KC = 16 (4 pieces, stride 16 dwords): a 2-bit code of
@@ -108,7 +127,11 @@ __device__ __forceinline__ void mm_region_geometry(MmRegion &u) {
 template <int R>
 __device__ __forceinline__ bool mm_region_fits_rt(int w, int h, int C) {
     const int pitch = ((w + 3) >> 2) * 4;
+#if GFN_MM_DEFAULT == 1
+    const int cap = C == 16 ? Mw<R, 16>::kCap : (C == 32 ? Mw<R, 32>::kCap : Mw<R, 64>::kCap);
+#else
     const int cap = C == 16 ? Mm<R, 16>::kCap : (C == 32 ? Mm<R, 32>::kCap : Mm<R, 64>::kCap);
+#endif
     return (long)pitch * h <= cap && w <= 252 && h <= 255;
 }
 

@@ -1,6 +1,7 @@
-"""GPU: the parked matrix-core local-correlation kernel (csrc/local_corr_mm.h, round 3) stays parity-green.  It is not the product
-path (the lean fp32 kernel is faster, profiles/r03_local_corr_mm.md); `gfnet_amd/build.py --mm` / __graft_entry__.build() compile
-it into libgfnet_hip_mm.so (-DGFN_MM_DEFAULT=1: default path of r >= 3), which a child process loads through GFNET_HIP_LIB.
+"""GPU: the parked r = 3 / 4 matrix-core local-correlation kernel (csrc/local_corr_mw.h on the helpers of csrc/local_corr_mm.h, round 3)
+stays parity-green.  It is not the product path (the lean fp32 kernel is faster, profiles/r03_local_corr_mm.md); `gfnet_amd/build.py
+--mm` / __graft_entry__.build() compile it into libgfnet_hip_mm.so (-DGFN_MM_DEFAULT=1: default path of r = 3, 4), which a child
+process loads through GFNET_HIP_LIB.  (The r >= 5 matrix-core kernel IS the product path: tests/test_local_corr_gpu.py.)
 Split-bf16 products: NOT bit-identical to the fp32 FMA kernels, within 1e-4 * max(1, |ref|) of the oracle."""
 import os
 import subprocess
