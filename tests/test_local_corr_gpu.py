@@ -186,6 +186,45 @@ def test_large_windows_on_the_matrix_core_vs_fp32_kernel_and_oracle(hs, G, r, fl
     assert_close(default, oracle.local_correlation((B, c, hs, hs), f0, f1.astype(np.float32), r, G, flow=flow), TOL, f"{flow_kind} vs oracle")
 
 
+def test_large_windows_edge_cases_rect_maps_tiny_grids_slices_and_wild_flows():
+    """The r >= 5 matrix-core path off the beaten track: rectangular maps and grids that are no multiple of the f0 quads (G = 5, 13, 22),
+    a single direction, f0 read from / out written into a concat slice (batch strides), non-finite and far-away flows (memory safety,
+    zeros padding)."""
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    c = 64
+    for (B, h, w, G, r, seed) in [(1, 23, 41, 13, 6, 701), (3, 40, 30, 5, 7, 702), (2, 38, 38, 22, 5, 703)]:
+        f0 = synth.lattice_normalish((B, c, G, G), seed)
+        f1 = synth.lattice_normalish((B, c, h, w), seed + 1)
+        flow = synth.homography_flow(B, G, seed + 2, scale=1.05)
+        assert_close(run(f0, f1, flow, r, G), oracle.local_correlation((B, c, h, w), f0, f1, r, G, flow=flow), TOL, f"rect {h}x{w} G{G} r{r}")
+    # concat slice in, concat slice out
+    B, hs, G, r = 2, 56, 32, 6
+    K = (2 * r + 1) ** 2
+    f0 = synth.lattice_normalish((B, c, G, G), 711)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 712)
+    flow = synth.homography_flow(B, G, 713)
+    d = torch.full((B, c + 7 + K, G, G), 3.0, device="cuda")
+    d[:, :c] = dev(f0)
+    local_correlation((B, c, hs, hs), d[:, :c], dev(f1), r, G, flow=dev(flow), out=d[:, c + 7:])
+    torch.cuda.synchronize()
+    assert_close(d[:, c + 7:].cpu().numpy(), oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow), TOL, "slice r6")
+    assert torch.all(d[:, c:c + 7] == 3.0)
+    # wild flows
+    flow = synth.homography_flow(B, G, 714)
+    flow[0, 0, 0, 0] = 1e30
+    flow[0, 1, 3, 3] = -1e9
+    flow[0, 0, 5, 5] = 50.0
+    flow[1, :, 7, 9] = np.nan
+    out = run(f0, f1, flow, r, G)
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    good = np.ones((B, G, G), bool)
+    good[0, 0, 0] = good[0, 3, 3] = good[1, 7, 9] = False  # coordinates beyond float->int range / nan: value unspecified, must not crash
+    for b in range(B):
+        assert_close(out[b][:, good[b]], ref[b][:, good[b]], TOL, "finite cells")
+    assert np.all(out[0][:, 5, 5] == 0)  # far outside the image: zeros padding
+
+
 def test_ragged_sizes_and_rect_maps():
     # G not a multiple of the tile, rectangular f1, batch of 3
     B, c, h, w, G, r = 3, 16, 37, 53, 21, 3
