@@ -895,8 +895,8 @@ bool mm_shape(int C, int H, int W, int G, int r, int f16) {
     const long K = (long)(2 * r + 1) * (2 * r + 1);
     // (one channel count per radius is built: GFNet's r = 4 on 32-channel maps, and r = 3 on 16 for the tests -- every further
     // instantiation of the persistent kernel costs ~40 s of compile time)
-    return kmm && C == (r == 4 ? 32 : 16) && !(f16 && (W & 1)) && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) &&
-           (long)C * G * G < (1L << 30);
+    // (fp32 maps only: the fp16 instantiations doubled the library's four-minute compile for a parked kernel; fp16 maps take the lean path)
+    return kmm && C == (r == 4 ? 32 : 16) && !f16 && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
 }
 
 // large windows on 64-channel maps: the matrix-core tile kernel of local_corr_mq.h is the first launch (byte offsets into the maps and
@@ -1028,7 +1028,7 @@ int launch_lean_path(const LcParams &p0, hipStream_t stream) {
 
 template <int R, int ROUNDS, typename FT>
 int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
-    if constexpr (Lean<R>::kMM) {
+    if constexpr (Lean<R>::kMM && sizeof(FT) == 4) {
         if (lean && p0.mm) return launch_mm<R, FT>(p0, stream);
     }
 #if defined(GFN_LEAN_R7) && GFN_LEAN_R7
