@@ -21,7 +21,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
 C, HS, G, R, B = $C, $HS, $G, $R, 64
 algo = 4 * B * (C * G * G + C * HS * HS + 2 * G * G + (2 * R + 1) ** 2 * G * G)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE and rocprofv3 --pmc WRITE_SIZE (separate passes), tools/pmc_hbm_local_corr.sh %d %d %d %d: "
-                 "tools/probe_local_corr_one.py, 64 directions, homography flows, 8 dispatches each, round 3 (lean tile path after the vector-memory diet)" % (C, HS, G, R),
+                 "tools/probe_local_corr_one.py, 64 directions, homography flows, 8 dispatches each" % (C, HS, G, R),
        "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is; both in KB",
        "algorithmic_bytes_per_launch": algo, "kernels": {}}
 tot = 0.0
@@ -33,7 +33,7 @@ for k, d in agg.items():
     out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1), "hbm_bytes_per_launch": int(b)}
     tot += b
 out["hbm_bytes_per_launch"] = int(tot)
-out["note"] = "sum over the launches of one gfn_local_corr_fwd call (plan + lean tile kernel [+ second launch on the round-1 path]): %.1f MB vs %.1f MB algorithmic" % (tot / 1e6, algo / 1e6)
+out["note"] = "sum over the launches of one gfn_local_corr_fwd call (plan + tile kernel [+ second launch]): %.1f MB vs %.1f MB algorithmic" % (tot / 1e6, algo / 1e6)
 json.dump(out, open("$JSON", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
