@@ -152,12 +152,39 @@ def self_launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    # Poll every child: if a rank dies at start-up (bad device, out of memory) the others would sit in the rendezvous or in the
+    # first barrier until the process-group timeout; on the first non-zero exit the siblings are terminated and that code returned.
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [rc for rc in rcs if rc not in (None, 0)]
+        if bad:
+            failed = abs(bad[0])
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = chunks[0] if chunks else ""
+    rcs = [p.returncode for p in procs]
     for line in out.splitlines():  # the JSON line on stdout, anything else a library wrote there on stderr
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
-    return max((abs(rc) for rc in rcs), default=0)
+    return failed or max((abs(rc) for rc in rcs if rc is not None), default=0)
 
 
 def dry_run(args):
@@ -167,6 +194,9 @@ def dry_run(args):
 
     from gfnet_amd import parallel
 
+    # test hook (tests/test_parallel_cpu.py): the named rank dies before the rendezvous, as a rank with a bad device would
+    if os.environ.get("GFN_BENCH_TEST_EXIT_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)
     rank, world, _ = parallel.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -506,7 +536,9 @@ def main():
                                "sample": f"{n_cpu} pair(s) per image size of the same workload through oracle/ (C + OpenMP), "
                                          "1 warm-up + median of 3"}
         sc_i = scenes.index(main_scene)
-        ace_o, ace_t = solve_parity(main_scene, outs[sc_i][1], outs[sc_i][0], min(2, B))
+        n_par = min(8, B)  # the CPU leg's cost is the oracle walk above, not the solve: eight pairs of the batch
+        ace_o, ace_t = solve_parity(main_scene, outs[sc_i][1], outs[sc_i][0], n_par)
+        out["corner_error_pairs"] = n_par
         out["mean_corner_error_vs_ref_px"] = ace_o
         out["mean_corner_error_vs_truth_px"] = ace_t
     if stack_leg is not None:

@@ -1059,6 +1059,9 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     // <= 80 KB (two workgroups per CU) for every shape GFNet uses; other C/r combinations still run,
     // one workgroup per CU; absurdly wide features go to the general kernel
     if (lds > kMaxLds) return -1000;
+    // r >= 5 stages through a 32-bit buffer descriptor (local_corr_stage.h): maps of 2 GiB and more would wrap its byte count and
+    // stage zeros; the general kernel (64-bit pointers) takes them
+    if (R >= 5 && (long)p.C * p.H * p.W * (long)sizeof(FT) >= 0x7FFFFFF0L) return -1000;
     // per call and unconditional: the attribute is per device, a process may drive several
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS, FT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -1211,11 +1214,18 @@ namespace {
 template <int R, typename FT>
 int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s, bool keep) {
     lean_window_params<R>(p);
-    const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
+    const bool quad = gfn_ri::ri_quads(q);  // four cells per thread (refiner_input.h)
+    const unsigned q_blocks = (unsigned)(((long)q.G * q.G / (quad ? 4 : 1) + 255) / 256);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
-    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
-    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    const dim3 grid(q_blocks + p_blocks, (unsigned)q.B);
+    if (quad) {
+        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true, true>), grid, dim3(256), 0, s, q, p, q_blocks);
+        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false, true>), grid, dim3(256), 0, s, q, p, q_blocks);
+    } else {
+        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), grid, dim3(256), 0, s, q, p, q_blocks);
+        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), grid, dim3(256), 0, s, q, p, q_blocks);
+    }
     return gfn::check_launch("refiner_input_plan_kernel");
 }
 }  // namespace

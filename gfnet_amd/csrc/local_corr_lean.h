@@ -231,11 +231,13 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
 // The refiner-input kernel and the plan of the local correlation that follows it in ConvRefiner.forward (network.py:537-555) in
 // ONE launch: blockIdx.x < q_blocks are refiner-input blocks of direction blockIdx.y, the rest plan that direction's tiles
 // (16 per block).  Both only read the flow; the plan's ~8 us and a kernel boundary disappear from the local-correlation call.
-template <int R, typename FT, bool KEEP>
+// QUAD: the refiner-input blocks take four cells per thread (refiner_input.h)
+template <int R, typename FT, bool KEEP, bool QUAD = false>
 __global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs q, LcParams p, unsigned q_blocks) {
     const int b = gfn_ri::ri_direction(q.B, q.Bh, blockIdx.y);
     if (blockIdx.x < q_blocks) {
-        gfn_ri::refiner_input_cell<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
+        if constexpr (QUAD) gfn_ri::refiner_input_quad<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
+        else gfn_ri::refiner_input_cell<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
         return;
     }
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
@@ -350,7 +352,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             }
         }
     };
-    f0_issue(0);
+    if (!ABL(p, 4)) f0_issue(0);
     // items of a chunk in flight per wave.  r <= 2: the 40 KB stage holds 512 positions = 512 lane items of a 16-channel chunk = one
     // item per lane, so a second register set only ever repeated the first item's loads -- half of the kernel's vector-memory
     // instructions, each a full trip through the texture-address path
@@ -364,7 +366,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
     QuadRegs<PRE, FT> pre;
-    quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
+    if (!ABL(p, 1)) quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
@@ -379,7 +381,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const unsigned long long slow_mask = __ballot(c.flag == kCellSlow);
         if (lane == 0) hdr[4] = __popcll(slow_mask);
     }
-    f0_commit();
+    if (!ABL(p, 4)) f0_commit();
     auto fill_table = [&](float cnx, float cny, int cX0, int cY0) {
         // fraction table: the reference's fp32 coordinate of every tap column / row of every cell (local_correlation.py:55 adds
         // window offsets in normalised units, grid_sample un-normalises).  lane = cell, wave = tap index: no division.  Read by the
@@ -436,12 +438,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd) addressing(rd, __shfl(c.X0, rd * 32 + cr), __shfl(c.Y0, rd * 32 + cr));
     }
     STAMP(2);
-    quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
-    quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
+    if (!ABL(p, 1)) {
+        quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
+        quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
+    }
     STAMP(3);
     __syncthreads();
     STAMP(4);
-    if (!kFlowAll) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+    if (!kFlowAll && !ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
     if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
 
     if (!kFlowAll) {
@@ -471,13 +475,14 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
-        if (more) {  // next step's loads: in flight across this D-stage
+        if (more && !ABL(p, 1)) {  // next step's loads: in flight across this D-stage
             quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
             if (F0CH) f0_issue(nch * kChunk);
         }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
+            if (ABL(p, 2)) continue;
             float f[kChunk];
             {
                 const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + (F0CH ? 0 : c0));
@@ -506,8 +511,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (more) {
             __syncthreads();  // everyone is done reading this step's pixels
             STAMP(7);
-            quad_commit<PRE, CHECK, FT>(s4, pre, H, W, un, wave, lane, qn, 0);
-            quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
+            if (!ABL(p, 1)) {
+                quad_commit<PRE, CHECK, FT>(s4, pre, H, W, un, wave, lane, qn, 0);
+                quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
+            }
             if (F0CH) f0_commit();
             __syncthreads();
             STAMP(8);
@@ -523,7 +530,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
             const int pp = s16 + 16 * t;
-            if (pp < P) dbuf[cell * DS + pp] = acc[rd][t];
+            if (pp < P && !ABL(p, 16)) dbuf[cell * DS + pp] = acc[rd][t];
         }
     }
     STAMP(11);
@@ -535,7 +542,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const int cell = ((ec >> 3) << 5) | (er << 3) | (ec & 7);
         const int gi = row0 + er, gj = col0 + ec;
         const int flag = cellFlag[cell];
-        if ((gi < G) & (gj < G) & !(flag & kCellSlow)) {
+        if ((gi < G) & (gj < G) & !(flag & kCellSlow) & !ABL(p, 8)) {
             const bool empty = (flag & kCellEmpty) != 0;
             const float *dc = dbuf + cell * DS;
             const float *tc = tab + cell * TS;
@@ -560,7 +567,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
                     for (int kx = 0; kx < D; ++kx) {
                         const float val = fmaf(m[kx + 1], wx1[kx], m[kx] * wx0[kx]);
-                        buf_st_nt(outr, goff, (unsigned)(ky * D + kx) * GG4, empty ? 0.f : val);  // streamed: nothing on the hot path reads it back
+                        if (!ABL(p, 128)) buf_st_nt(outr, goff, (unsigned)(ky * D + kx) * GG4, empty ? 0.f : val);
+                        else asm volatile("" :: "v"(val));  // streamed: nothing on the hot path reads it back
                     }
                 }
             }
@@ -634,6 +642,7 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     RowPlan uA, uB;
     uA.x0 = pl[0]; uA.y0 = pl[1]; uA.w = pl[2] & 0xffff; uA.h = pl[2] >> 16;
     uB.x0 = pl[4]; uB.y0 = pl[5]; uB.w = pl[6] & 0xffff; uB.h = pl[6] >> 16;
+    if (ABL(p, 64)) { uA.h = min(uA.h, 7); uB.h = min(uB.h, 7); }  // timing experiment: what a row ring would stage per tile
     (void)region_fits<R>(uA);         // pitch, quads per row, rows per item, items (the plan launch checked that they fit)
     (void)region_fits<R>(uB);
     const bool interior = (flags & kPlanInterior) != 0;

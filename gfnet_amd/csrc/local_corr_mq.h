@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_mq_kernel(LcParams p) 
         // constraint) it takes the tile here and now (fp32 FMAs; on the raw soft-argmax flows of stride 16 a third of the tiles:
         // sent to the list they doubled the second launch, 47 -> 104 us at 448); the rest goes to the second launch's list.
         if (path == 2) {
+            if (tid == 0 && (wid & 7u) == 0) atomicAdd(p.todo + 6, 8);  // informational, sampled (header word 6 -> 7: tiles the fp32 routine took here)
             __syncthreads();  // LDS is laid out anew
             process_tile<R, 1, true, kTileW, false, FT>(p, b, row0, col0, 2, wid, smem);
         } else if (tid == 0) {

@@ -127,6 +127,51 @@ def test_full_batch_local_correlation_vs_oracle(c, hs, G, r, S):
     assert_close(host(out), host(old), 1e-4, "default path (matrix-core D-stage where enabled) vs the fp32 FMA kernels")
 
 
+def _raw_softargmax_flows(B, S, seed):
+    """The flows scale 16 really sees: the raw output of corr_softargmax on a synthetic scene's coarsest maps (near one-hot
+    soft-argmax: cell centres of the other image, which scatter a third of the r = 7 tiles past the matrix-core kernel's
+    accumulators).  Returns (flow (B,2,G,G) numpy, f-maps side)."""
+    from gfnet_amd import _synthetic as synthetic, ops
+
+    gen_cpu = torch.Generator().manual_seed(seed)
+    gen = torch.Generator(device="cuda").manual_seed(seed + 1)
+    H = synthetic.random_homographies(B // 2, S, gen_cpu)
+    pa, pb = synthetic.make_pyramids(H, S, ["16"], torch.device("cuda"), gen, torch.float32)
+    flow = ops.corr_softargmax(pa["16"], pb["16"], symmetric=True)
+    return host(flow).astype(np.float32)
+
+
+@pytest.mark.parametrize("c,hs,G,r,S", [(64, 32, 32, 7, 448), (64, 56, 32, 6, 448), (64, 70, 40, 6, 448), (64, 48, 48, 7, 672)])
+def test_full_batch_large_windows_vs_oracle(c, hs, G, r, S):
+    """The r >= 5 matrix-core kernel (csrc/local_corr_mq.h, the default path of basic.json's radius [7, 6, ...]) at the production
+    batch: 64 directions at 448 (32 at 672), whole tensor against the oracle.  The r = 7 cases run on the raw soft-argmax flows of
+    a synthetic scene -- the flows that send a third of the tiles through the fp32 routine inside the launch and some to the
+    second launch -- and all three routes of a tile must have been taken there (counters in the scratch header)."""
+    import synth
+    from gfnet_amd import _lib
+    from gfnet_amd.utils.local_correlation import local_correlation
+
+    B = 64 if S == 448 else 32
+    f0 = synth.lattice_normalish((B, c, G, G), 801 + r)
+    f1 = synth.lattice_normalish((B, c, hs, hs), 802 + r)
+    flow = _raw_softargmax_flows(B, S, 803 + r) if r == 7 else _bench_flows(B, G, S, 803 + r)
+    assert flow.shape == (B, 2, G, G)
+    out = local_correlation((B, c, hs, hs), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G, flow=torch.from_numpy(flow).cuda())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hdr = _lib.scratch(dev, int(_lib.lib().gfn_local_corr_scratch_bytes(B, G)))[:8].cpu().numpy()  # csrc/local_corr.hip kTodoHdr
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    assert_close(host(out), ref, 1e-4, f"full batch c{c} hs{hs} G{G} r{r}")
+    tiles = B * ((G + 1) // 2) * ((G + 15) // 16)
+    listed, in_launch = int(hdr[3]), int(hdr[7])
+    if r == 7:
+        assert listed > 0, "no tile went to the second launch"
+        assert in_launch > 0, "no tile took the fp32 routine inside the launch"
+        assert listed + in_launch < tiles, "no tile took the matrix-core path"
+    old = local_correlation((B, c, hs, hs), torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), r, G, flow=torch.from_numpy(flow).cuda(),
+                            _variant=2)
+    assert_close(host(out), host(old), 1e-4, "matrix-core path vs the fp32 FMA kernel")
+
+
 @pytest.mark.parametrize("G,S", [(48, 672), (96, 672), (192, 672), (384, 672), (16, 224), (32, 224), (64, 224), (128, 224)])
 def test_grid_ops_on_the_672_and_224_grids(G, S):
     """refiner_input, flow_update, the inter-scale resize and match_post on the grids of configs[2] / configs[4] (round 1

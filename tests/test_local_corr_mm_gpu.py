@@ -1,6 +1,6 @@
 """GPU: the parked r = 3 / 4 matrix-core local-correlation kernel (csrc/local_corr_mw.h on the helpers of csrc/local_corr_mm.h, round 3)
 stays parity-green.  It is not the product path (the lean fp32 kernel is faster, profiles/r03_local_corr_mm.md); `gfnet_amd/build.py
---mm` / __graft_entry__.build() compile it into libgfnet_hip_mm.so (-DGFN_MM_DEFAULT=1: default path of r = 3, 4), which a child
+--mm` (or __graft_entry__.build() with GFN_BUILD_MM=1; opt-in since round 4) compile it into libgfnet_hip_mm.so (-DGFN_MM_DEFAULT=1: default path of r = 3, 4), which a child
 process loads through GFNET_HIP_LIB.  (The r >= 5 matrix-core kernel IS the product path: tests/test_local_corr_gpu.py.)
 Split-bf16 products: NOT bit-identical to the fp32 FMA kernels, within 1e-4 * max(1, |ref|) of the oracle."""
 import os
@@ -54,7 +54,8 @@ print("MM_PARITY_OK worst", worst)
 
 
 def test_matrix_core_kernel_matches_the_oracle():
-    assert os.path.exists(MM_LIB), "libgfnet_hip_mm.so missing: run `python -m gfnet_amd.build --mm` (or __graft_entry__.build())"
+    if not os.path.exists(MM_LIB):  # opt-in build (a second four-minute compile for a kernel that is not the product path)
+        pytest.skip("libgfnet_hip_mm.so not built: `python -m gfnet_amd.build --mm` or GFN_BUILD_MM=1 with __graft_entry__.build()")
     env = dict(os.environ, GFNET_HIP_LIB=MM_LIB, GFN_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -109,3 +109,14 @@ def test_bench_child_failure_is_the_parents_return_code():
     """--gpus 2 given to ranks whose environment says WORLD_SIZE=1 must fail loudly (a mismatch is never papered over)."""
     rc, js, err = _bench("--gpus", "2", "--dry-run", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert rc != 0 and not js
+
+
+def test_bench_a_rank_dying_at_start_up_ends_the_run_at_once():
+    """Rank 1 exits with code 3 before the rendezvous: the parent must terminate rank 0 (which would otherwise wait in the
+    rendezvous until the process-group timeout) and hand that code back, within seconds."""
+    import time
+
+    t0 = time.time()
+    rc, js, err = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", env={"GFN_BENCH_TEST_EXIT_RANK": "1"})
+    assert rc == 3 and not js, (rc, err[-500:])
+    assert time.time() - t0 < 120
