@@ -22,11 +22,6 @@ template <typename FT, bool KEEP>
 __global__ __launch_bounds__(256) void refiner_input_kernel(RiArgs q) {
     refiner_input_cell<FT, KEEP>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * 256u + threadIdx.x);
 }
-// four consecutive cells of a grid row per thread (refiner_input.h: 16-byte stores, 7/4 maps read by runs)
-template <typename FT, bool KEEP>
-__global__ __launch_bounds__(256, 4) void refiner_input_quad_kernel(RiArgs q) {
-    refiner_input_quad<FT, KEEP>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * blockDim.x + threadIdx.x);
-}
 
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
                                                           float *__restrict__ out, long out_bs, int B, int C, int H, int W,
@@ -259,19 +254,6 @@ GFN_EXPORT int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtyp
     q.fa = f0; q.fb = f1; q.flow = flow; q.dw = disp_w; q.db = disp_b; q.d = d; q.d_bs = (long)d_bs;
     q.B = B; q.Bh = (symmetric & 1) ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
     const bool keep = (symmetric & 2) != 0;  // the grid_feature planes are already in d (GFN_RI_KEEP_GRID_FEATURE)
-    if (gfn_ri::ri_quads(q)) {
-        // few directions (a single pair): one wave per workgroup, so that the quarter of the threads still spreads over the chip
-        const unsigned bt = (long)G * G / 4 * B >= 4L * 256 * 256 ? 256u : 64u;
-        const dim3 gq((unsigned)(((long)G * G / 4 + bt - 1) / bt), (unsigned)B), bq(bt);
-        if (dtype == GFN_F16) {
-            if (keep) hipLaunchKernelGGL((refiner_input_quad_kernel<_Float16, true>), gq, bq, 0, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((refiner_input_quad_kernel<_Float16, false>), gq, bq, 0, (hipStream_t)stream, q);
-        } else {
-            if (keep) hipLaunchKernelGGL((refiner_input_quad_kernel<float, true>), gq, bq, 0, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((refiner_input_quad_kernel<float, false>), gq, bq, 0, (hipStream_t)stream, q);
-        }
-        return gfn::check_launch("refiner_input_quad_kernel");
-    }
     if (dtype == GFN_F16) {
         if (keep) hipLaunchKernelGGL((refiner_input_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream, q);
         else hipLaunchKernelGGL((refiner_input_kernel<_Float16, false>), grid, dim3(256), 0, (hipStream_t)stream, q);

@@ -1214,18 +1214,11 @@ namespace {
 template <int R, typename FT>
 int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s, bool keep) {
     lean_window_params<R>(p);
-    const bool quad = gfn_ri::ri_quads(q);  // four cells per thread (refiner_input.h)
-    const unsigned q_blocks = (unsigned)(((long)q.G * q.G / (quad ? 4 : 1) + 255) / 256);
+    const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
-    const dim3 grid(q_blocks + p_blocks, (unsigned)q.B);
-    if (quad) {
-        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true, true>), grid, dim3(256), 0, s, q, p, q_blocks);
-        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false, true>), grid, dim3(256), 0, s, q, p, q_blocks);
-    } else {
-        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), grid, dim3(256), 0, s, q, p, q_blocks);
-        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), grid, dim3(256), 0, s, q, p, q_blocks);
-    }
+    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
     return gfn::check_launch("refiner_input_plan_kernel");
 }
 }  // namespace

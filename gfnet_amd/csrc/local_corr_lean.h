@@ -231,13 +231,11 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
 // The refiner-input kernel and the plan of the local correlation that follows it in ConvRefiner.forward (network.py:537-555) in
 // ONE launch: blockIdx.x < q_blocks are refiner-input blocks of direction blockIdx.y, the rest plan that direction's tiles
 // (16 per block).  Both only read the flow; the plan's ~8 us and a kernel boundary disappear from the local-correlation call.
-// QUAD: the refiner-input blocks take four cells per thread (refiner_input.h)
-template <int R, typename FT, bool KEEP, bool QUAD = false>
+template <int R, typename FT, bool KEEP>
 __global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs q, LcParams p, unsigned q_blocks) {
     const int b = gfn_ri::ri_direction(q.B, q.Bh, blockIdx.y);
     if (blockIdx.x < q_blocks) {
-        if constexpr (QUAD) gfn_ri::refiner_input_quad<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
-        else gfn_ri::refiner_input_cell<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
+        gfn_ri::refiner_input_cell<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
         return;
     }
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);

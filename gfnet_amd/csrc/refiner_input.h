@@ -4,8 +4,6 @@
 #pragma once
 #include "common.h"
 
-#include <type_traits>
-
 namespace gfn_ri {
 
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * (float)size - 1.f) / 2.f; }
@@ -204,172 +202,5 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
     for (int k = 0; k < Dd; ++k) __builtin_nontemporal_store(dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k], o + (size_t)(2 * C + k) * GG + cell);
 }
 
-
-// ---- four cells per thread (round 4) --------------------------------------------------------------------------------------------
-// The per-cell kernel above issues one 4-byte store and two 8-byte gathers per cell, channel and map: at 64 lanes x 4 bytes a
-// wave-level store moves 256 bytes, and the CU's vector-memory path takes about as long for it as for a 1 KB one (measured: ~37 cycles
-// per wave-level memory instruction at every scale, whatever its width).  Here a thread owns FOUR consecutive cells of a grid row:
-//   * every plane is written with 16-byte stores (a quarter of the store instructions);
-//   * the regular-grid sample (grid_feature, network.py:539-547) of a map that is 7/4 of the grid -- every scale of GFNet but the
-//     coarsest -- touches the same 7 consecutive pixels of two image rows for the four cells, at the fixed offsets {0, 2, 3, 5}: two
-//     loads per row (16 + 12 bytes, 4-byte aligned) instead of four 8-byte gathers.  The pattern is CHECKED per wave from the same
-//     fp32 coordinate arithmetic (not assumed from the sizes); waves where it does not hold gather pairs like the per-cell kernel;
-//   * x_hat follows the flow: pair gathers as before.
-// Products and sums are those of refiner_input_cell in the same order: results are bit-identical.
-#ifndef GFN_RI_QUAD_NCH
-#define GFN_RI_QUAD_NCH 1
-#endif
-typedef float f32x4a __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-
-template <typename FT, bool KEEP = false>
-__device__ __forceinline__ void refiner_input_quad(const RiArgs &args, int b, unsigned quad) {
-    const FT *__restrict__ fa = static_cast<const FT *>(args.fa);
-    const FT *__restrict__ fb = static_cast<const FT *>(args.fb);
-    const float *__restrict__ flow = args.flow, *__restrict__ dw = args.dw, *__restrict__ db = args.db;
-    float *__restrict__ d = args.d;
-    const long d_bs = args.d_bs;
-    const int Bh = args.Bh, C = args.C, Hs = args.Hs, Ws = args.Ws, G = args.G, Dd = args.Dd;
-    const float disp_scale = args.disp_scale;
-    const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
-    const unsigned plane = (unsigned)(Hs * Ws), GG = (unsigned)(G * G);
-    const unsigned cell = quad * 4u;
-    if (cell >= GG) return;
-    const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
-    const FT *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
-    const FT *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
-    const float cy = gfn::linspace_at(lo, hi, G, i);
-    const float *fl = flow + (size_t)b * 2 * GG;
-    const f32x4a fx = *reinterpret_cast<const f32x4a *>(fl + cell), fy = *reinterpret_cast<const f32x4a *>(fl + GG + cell);
-    float *o = d + (size_t)b * d_bs;
-    float cx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cx[k] = gfn::linspace_at(lo, hi, G, j + k);
-    // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
-    for (int e = 0; e < Dd; ++e) {
-        const float w0 = dw[e * 2 + 0], w1 = dw[e * 2 + 1], bias = db[e];
-        f32x4a v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = w0 * (disp_scale * (fx[k] - cx[k])) + w1 * (disp_scale * (fy[k] - cy)) + bias;
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4a *>(o + (size_t)(2 * C + e) * GG + cell));
-    }
-    BilinP sa[4], sb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!KEEP) sa[k] = bilin_pairs(cx[k], cy, Ws, Hs);  // grid_feature = grid_sample(x, im_A_coords)   network.py:547
-        sb[k] = bilin_pairs(fx[k], fy[k], Ws, Hs);          // x_hat = grid_sample(y, flow)                 network.py:537
-    }
-    // the 7/4 pattern: pairs of the four cells start at +0, +2, +3, +5 of one 7-pixel run, both rows inside the map, one below the other
-    bool fast = false;
-    if (!KEEP && sizeof(FT) == 4) {
-        fast = (sa[1].o[0] == sa[0].o[0] + 2u) & (sa[2].o[0] == sa[0].o[0] + 3u) & (sa[3].o[0] == sa[0].o[0] + 5u) & (sa[0].o[1] == sa[0].o[0] + (unsigned)Ws);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fast &= (sa[k].o[1] == sa[k].o[0] + (unsigned)Ws);
-        fast = __all(fast);
-    }
-    constexpr int NCH = GFN_RI_QUAD_NCH;  // channels in flight per thread: each 14 + 16 loaded values (runs) or 32 (pairs)
-    // one loop per form (the choice is wave-uniform and made once: neither loop carries the other's offsets and loads)
-    auto channels = [&](auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        for (int c0 = 0; c0 < C; c0 += NCH) {
-            f32x2u vb[NCH][4][2];
-#pragma unroll
-            for (int n = 0; n < NCH; ++n) {
-                const FT *sp = sm + (size_t)min(c0 + n, C - 1) * plane;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) vb[n][k][e] = ld_pair(sp + sb[k].o[e]);
-            }
-            if constexpr (!KEEP && FAST && sizeof(FT) == 4) {
-                f32x4u lo4[NCH][2];
-                f32x3u hi3[NCH][2];
-#pragma unroll
-                for (int n = 0; n < NCH; ++n) {
-                    const float *qp = reinterpret_cast<const float *>(q) + (size_t)min(c0 + n, C - 1) * plane;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        lo4[n][e] = *reinterpret_cast<const f32x4u *>(qp + sa[0].o[e]);
-                        hi3[n][e] = *reinterpret_cast<const f32x3u *>(qp + sa[0].o[e] + 4);
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < NCH; ++n) {
-                    if (c0 + n < C) {
-                        f32x4a r;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float ra = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                // pixels +0..+6 of the run: cell k's pair sits at {0, 2, 3, 5}[k]
-                                const float pl = k == 0 ? lo4[n][e][0] : k == 1 ? lo4[n][e][2] : k == 2 ? lo4[n][e][3] : hi3[n][e][1];
-                                const float pr = k == 0 ? lo4[n][e][1] : k == 1 ? lo4[n][e][3] : k == 2 ? hi3[n][e][0] : hi3[n][e][2];
-                                ra += pl * sa[k].w[2 * e];
-                                ra += pr * sa[k].w[2 * e + 1];
-                            }
-                            r[k] = ra;
-                        }
-                        *reinterpret_cast<f32x4a *>(o + (size_t)(c0 + n) * GG + cell) = r;  // read back at once as the local correlation's f0: stays cached
-                    }
-                }
-            } else if constexpr (!KEEP) {
-                f32x2u va[NCH][4][2];
-#pragma unroll
-                for (int n = 0; n < NCH; ++n) {
-                    const FT *qp = q + (size_t)min(c0 + n, C - 1) * plane;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) va[n][k][e] = ld_pair(qp + sa[k].o[e]);
-                }
-#pragma unroll
-                for (int n = 0; n < NCH; ++n) {
-                    if (c0 + n < C) {
-                        f32x4a r;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float ra = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                ra += va[n][k][e].x * sa[k].w[2 * e];
-                                ra += va[n][k][e].y * sa[k].w[2 * e + 1];
-                            }
-                            r[k] = ra;
-                        }
-                        *reinterpret_cast<f32x4a *>(o + (size_t)(c0 + n) * GG + cell) = r;
-                    }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NCH; ++n) {
-                if (c0 + n < C) {
-                    f32x4a r;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float rb = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            rb += vb[n][k][e].x * sb[k].w[2 * e];
-                            rb += vb[n][k][e].y * sb[k].w[2 * e + 1];
-                        }
-                        r[k] = rb;
-                    }
-                    __builtin_nontemporal_store(r, reinterpret_cast<f32x4a *>(o + (size_t)(C + c0 + n) * GG + cell));
-                }
-            }
-        }
-    };
-    if (fast) channels(std::true_type{});   // wave-uniform
-    else channels(std::false_type{});
-}
-
-// shapes the four-cells-per-thread form takes: whole quads per grid row, 16-byte aligned planes, maps of two columns and more, and
-// grids large enough that a quarter of the threads still fills the chip (GFNet: scales 2 and 1, most of the step's refiner-input time;
-// the small grids of scales 16 / 8 / 4 keep one cell per thread: 4x the workgroups)
-inline bool ri_quads(const RiArgs &q) {
-    return (q.G % 4) == 0 && q.G >= 128 && q.Ws >= 2 && ((uintptr_t)q.d & 15) == 0 && (q.d_bs % 4) == 0 && ((uintptr_t)q.flow & 15) == 0;
-}
 
 }  // namespace gfn_ri

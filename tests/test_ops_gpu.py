@@ -539,49 +539,3 @@ def test_refiner_input_reuse_keeps_grid_feature(c, hs, G, r, dtype):
     with pytest.raises(ValueError):
         ops.refiner_input(G, x, y, flow2, w, b, r, scale_factor=1.25, corr_in_other=r > 0, reuse=d1[:, :-1].contiguous())
 
-
-@pytest.mark.parametrize("c,hs,G,r,Dd", [(16, 224, 128, 2, 16), (8, 448, 256, 0, 8), (16, 200, 128, 2, 5), (8, 280, 160, 0, 8), (4, 2, 128, 0, 3)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_refiner_input_four_cells_per_thread_is_bit_identical_to_one_cell_per_thread(c, hs, G, r, Dd, dtype):
-    """Round 4: on grids of 128 cells a side and more a thread owns four consecutive cells (16-byte stores; 7/4 maps read as runs of
-    seven pixels).  Same products, same order: bit-identical to the one-cell-per-thread kernel -- which a `d` that is not 16-byte
-    aligned still gets, through the C ABI -- on 7/4 maps (the run form), other ratios (the pair form), flows that leave the image,
-    symmetric batches, the keep-grid-feature mode, fp32 and fp16 maps; and against the oracle."""
-    from gfnet_amd import _lib, ops
-
-    g = torch.Generator().manual_seed(11 + G + c)
-    Bi = 2
-    x = torch.randn(Bi, c, hs, hs, generator=g).cuda().to(dtype)
-    y = torch.randn(Bi, c, hs, hs, generator=g).cuda().to(dtype)
-    w, bias = torch.randn(Dd, 2, generator=g).cuda(), torch.randn(Dd, generator=g).cuda()
-    flow = np.concatenate((synth.homography_flow(Bi, G, 911), 1.15 * synth.lattice_uniform((Bi, 2, G, G), 912))).astype(np.float32)
-    flow[0, 0, :, :7] -= np.float32(0.5)   # a band of samples left of the image
-    flow = dev(flow)
-    B, CH = 2 * Bi, 2 * c + Dd
-    d = ops.refiner_input(G, x, y, flow, w, bias, r, scale_factor=1.25, corr_in_other=False)
-    assert d.data_ptr() % 16 == 0
-    L = _lib.lib()
-    dt = _lib.GFN_F16 if dtype == torch.float16 else _lib.GFN_F32
-
-    def one_cell(mode, init=None):
-        buf = torch.empty(B * CH * G * G + 1, device="cuda", dtype=torch.float32)
-        dm = buf[1:].view(B, CH, G, G)  # 4 bytes off a 16-byte boundary: the one-cell-per-thread kernel takes the call
-        if init is not None:
-            dm.copy_(init)
-        _lib.check(L.gfn_refiner_input_fwd_dt(_lib.ptr(x), _lib.ptr(y), dt, _lib.ptr(flow), _lib.ptr(w.reshape(-1, 2).contiguous()), _lib.ptr(bias),
-                                              _lib.c_vp(dm.data_ptr()), CH * G * G, B, c, hs, hs, G, Dd, float(40 / 32 * 1.25), mode,
-                                              _lib.stream_ptr(flow.device)), "gfn_refiner_input_fwd_dt")
-        return dm
-
-    ref = one_cell(1)
-    assert torch.equal(d, ref)
-    xs, ys = np.concatenate((host(x.float()), host(y.float()))), np.concatenate((host(y.float()), host(x.float())))
-    assert_close(host(d), oracle.refiner_input(G, xs, ys, host(flow), host(w).reshape(Dd, 2, 1, 1), host(bias), 0, scale_factor=1.25,
-                                               corr_in_other=False), TOL, "d vs oracle")
-    # second iteration at the scale: grid_feature planes kept, the rest rewritten (GFN_RI_KEEP_GRID_FEATURE)
-    flow2 = (flow + 0.03).contiguous()
-    fresh = ops.refiner_input(G, x, y, flow2, w, bias, r, scale_factor=1.25, corr_in_other=False)
-    kept = ops.refiner_input(G, x, y, flow2, w, bias, r, scale_factor=1.25, corr_in_other=False, reuse=d)
-    assert torch.equal(kept, fresh)
-    flow, d = flow2, None
-    assert torch.equal(one_cell(3, init=fresh), fresh)
