@@ -269,7 +269,7 @@ class SceneRunner:
         return outs
 
 
-def secondary_workload(key, conv_stack, dev, rank, steps):
+def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     """A few steps of another BASELINE configuration after the timed region of the default line (configs[2] and
     configs[4] were builder-run only): whole-step rate and the roofline fraction of its own scale-4 local-correlation call."""
     import numpy as np
@@ -284,6 +284,7 @@ def secondary_workload(key, conv_stack, dev, rank, steps):
         scenes = [Scene(S, wl["pairs"], wl["num_itr"], dtype, conv_stack, dev, rank) for S in wl["sizes"]]
     main_scene = scenes[min(1, len(scenes) - 1)]
     runner = SceneRunner(scenes)
+    graphs, graph_note = False, None
     with torch.inference_mode():
         for i in range(4):  # (the three-scene workload needs more than two steps to settle: allocator, stream pools)
             runner.step(i)
@@ -298,20 +299,64 @@ def secondary_workload(key, conv_stack, dev, rank, steps):
             for i in range(steps):
                 runner.step(0)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt_eager = time.perf_counter() - t0
         finally:
             gc.enable()
         events = ops.kernel_events[main_scene.roofline_key]
+        # the same op with nothing beside it: the middle scene alone on the current stream (with several scenes the timed steps run
+        # their streams concurrently and the op shares the chip)
+        ops.kernel_events = {main_scene.roofline_key: []}
+        for i in range(3):
+            main_scene.step(0)
+        torch.cuda.synchronize()
+        events_alone = ops.kernel_events[main_scene.roofline_key]
         ops.kernel_events = None
+        dt = dt_eager
+        if use_graphs:
+            # every scene's step captured once into a hipGraph on a stream of its own, a timed step = one replay per scene: the
+            # host issues 3 launches per step instead of ~300 (Scene.capture).  Eager stays the fallback: never re-exec'ed, and a
+            # capture that fails only costs this leg its graph numbers.
+            try:
+                for sc in scenes:
+                    sc.capture(0)
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    for sc in scenes:
+                        sc.replay()
+                torch.cuda.synchronize()
+                gc.collect()
+                gc.disable()
+                try:
+                    t0 = time.perf_counter()
+                    for i in range(steps):
+                        for sc in scenes:
+                            sc.replay()
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                finally:
+                    gc.enable()
+                graphs = True
+            except Exception as e:  # noqa: BLE001 -- whatever the capture trips over, the eager numbers stand
+                graph_note = f"graph capture failed, eager numbers reported: {type(e).__name__}: {str(e)[:200]}"
+                torch.cuda.synchronize()
     pairs = wl["pairs"] * len(scenes)
     S0 = main_scene.size
     us = float(np.mean([a.elapsed_time(b) for a, b in events])) * 1e3
     fbytes = 2 if dtype == torch.float16 and ops.NATIVE_FP16 else 4
     nbytes = algorithmic_bytes_local_corr(2 * wl["pairs"], 32, side_of("4", S0), main_scene.grids[2], 4, fbytes)
-    return {"value": round(pairs * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "pairs_per_step": pairs, "workload": wl["label"],
-            "roofline_op": f"scale-4 local correlation, c32, {side_of('4', S0)}x{side_of('4', S0)}, G{main_scene.grids[2]}, r4, {2 * wl['pairs']} directions",
-            "roofline_avg_launch_us": round(us, 2), "roofline_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    out = {"value": round(pairs * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "pairs_per_step": pairs, "workload": wl["label"],
+           "mode": ("hipGraph replay: one captured step per scene and stream (seeds of the capture)" if graphs else "eager launches"),
+           "eager": {"value": round(pairs * steps / dt_eager, 2), "ms_per_step": round(dt_eager / steps * 1e3, 3)},
+           "roofline_op": f"scale-4 local correlation, c32, {side_of('4', S0)}x{side_of('4', S0)}, G{main_scene.grids[2]}, r4, {2 * wl['pairs']} directions",
+           "roofline_timed_in": "the eager steps (HIP events around the C-ABI call; with several scenes their streams run concurrently)",
+           "roofline_avg_launch_us": round(us, 2), "roofline_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    us_alone = float(np.mean([a.elapsed_time(b) for a, b in events_alone])) * 1e3
+    out["roofline_avg_launch_us_alone"] = round(us_alone, 2)
+    out["roofline_frac_alone"] = round(nbytes / (us_alone * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    if graph_note:
+        out["note"] = graph_note
+    return out
 
 
 def main():

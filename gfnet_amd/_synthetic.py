@@ -180,3 +180,35 @@ class Scene:
     def step(self, seed):
         warp, cert = self.match()
         return self.finish(warp, cert, seed)
+
+    # ---- a step as a hipGraph -----------------------------------------------------------------------------------------------------
+    # The small scenes of the pyramid workload are bound by the host's launch rate (~300 launches of 15-60 us kernels per step from
+    # Python / ctypes).  Every C-ABI entry point launches on the caller's stream, allocates nothing and keeps its scratch per
+    # stream, so a whole step -- both passes of the coarse-to-fine loop, sampling, solve -- captures into ONE graph
+    # (torch.cuda.graph: tensors the Python layer creates inside the capture live in the graph's private pool) and replays with a
+    # single launch.  Seeds are kernel arguments: a replay repeats the draws of its capture (re-capture, or run eagerly, for fresh
+    # draws per batch); timing hooks (ops.kernel_events / kernel_counters) must be off while capturing.
+    def capture(self, seed=0, warmup=2):
+        """Capture step(seed) on a stream of its own; returns the static output tensors (H, good matches) every replay() refills."""
+        from gfnet_amd import ops
+
+        if ops.kernel_events is not None or ops.kernel_counters is not None:
+            raise RuntimeError("Scene.capture: switch ops.kernel_events / ops.kernel_counters off first (they record events / synchronise)")
+        self._gstream = torch.cuda.Stream()
+        self._gstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._gstream):
+            for _ in range(warmup):  # lazy module state, the stream's scratch buffers, the allocator's pools
+                self.step(seed)
+        self._gstream.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=self._gstream):
+            self._graph_out = self.step(seed)
+        torch.cuda.current_stream().wait_stream(self._gstream)
+        return self._graph_out
+
+    def replay(self):
+        """One captured step on the capture stream; returns the static outputs (valid once that stream has caught up)."""
+        with torch.cuda.stream(self._gstream):
+            self._graph.replay()
+        return self._graph_out
+

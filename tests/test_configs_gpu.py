@@ -263,3 +263,31 @@ def test_fp16_refiner_input_and_corr_softargmax_match_the_widened_copy():
         a, b = ops.corr_softargmax(f0, f1, symmetric=sym), ops.corr_softargmax(f0.float(), f1.float(), symmetric=sym)
         np.testing.assert_array_equal(host(a), host(b))
     assert_close(host(ops.corr_softargmax(f0, f1)), oracle.corr_softargmax(host(f0), host(f1)), 1e-4, "corr_softargmax fp16")
+
+
+def test_a_scene_step_replayed_from_a_hipgraph_equals_the_eager_step():
+    """Round 4: a whole step (both passes of the coarse-to-fine loop, sampling, solve: ~300 launches) captured once into a hipGraph
+    (Scene.capture: torch.cuda.graph around the C-ABI launches, which allocate nothing and run on the caller's stream) and replayed:
+    H and the sampled matches are bit-identical to the eager step with the same seeds, replay after replay.
+    (The comparisons run on the capture stream: on ROCm 7.2 default-stream work on tensors of the eager steps BETWEEN two replays of
+    the full-step graph ends the next replay with a memory fault -- reproduced with tools/dbg_graph.py, not with the matching or the
+    sampling + solve captured alone, cause not found)"""
+    from gfnet_amd._synthetic import Scene
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with torch.inference_mode(False):
+        sc = Scene(224, 2, [1] * 5, torch.float16, "off", dev, 0)
+    with torch.inference_mode():
+        torch.manual_seed(7)  # the sampler's seeds come from torch's CPU generator: three steps eagerly, the third is the reference
+        for _ in range(3):
+            He, ge = sc.step(5)
+        He, ge = He.clone(), ge.clone()
+        torch.cuda.synchronize()
+        torch.manual_seed(7)  # capture() runs two warm-up steps, then captures the third
+        Hg, gg = sc.capture(5, warmup=2)
+        for _ in range(3):
+            sc.replay()
+            with torch.cuda.stream(sc._gstream):
+                same = bool(torch.equal(Hg, He)) and bool(torch.equal(gg, ge))
+                finite = bool(torch.isfinite(Hg).all())
+            assert same and finite
