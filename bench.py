@@ -105,6 +105,20 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def timed_loop(fn, n, sync):
+    """n calls of fn between two sync()s, without collector pauses (one GC policy for every timed leg)."""
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = fn(i)
+        sync()
+        return time.perf_counter() - t0, r
+    finally:
+        gc.enable()
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,9 +136,11 @@ def parse_args():
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="two streams per scene inside the timed region: a step's sampling + solve run under the next step's match "
-                         "(default: one stream per scene; the default 448b32 line reports the pipelined rate as `pipelined_steps`)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="one stream per scene inside the timed region (default: two -- a step's sampling + solve run on a second stream under "
+                         "the next step's match, the way gfnet_amd.evaluate streams batches; the roofline op is timed in separate, "
+                         "un-overlapped steps either way, and the default line reports the one-stream rate as `unpipelined_steps`)")
+    ap.set_defaults(pipeline=True)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="take the self-launch path (parent starts the rank processes, relays rank 0's line) also for --gpus 1: the "
@@ -435,12 +451,20 @@ def main():
                 (gm, _), t_sample = timed(lambda: sample_batched(m, warp, cert, 5000))
                 _, t_solve = timed(lambda: estimate_homographies(gm, sc.sizes, iters=m.ransac_iters, seed=0))
                 print(f"[breakdown] {sc.size}: match({sc.size}+{sc.up}) {t_match:.2f} ms | sample {t_sample:.2f} ms | solve {t_solve:.2f} ms", file=sys.stderr)
+        dt, (Hall, outs) = timed_loop(lambda i: step(0), args.steps, sync)
+        # The roofline op is timed in steps of its own, on ONE stream per scene with nothing beside it (in the pipelined timed region
+        # the previous step's sampling + solve share the chip with it: 96 -> 107 us in round 3), HIP events around the C-ABI call.
+        plain = runner if not args.pipeline else SceneRunner(scenes, pipeline=False)
+
+        def plain_step(seed):
+            outs_ = plain.step(seed)
+            return parallel.gather_homographies(torch.cat([o[0] for o in outs_])), outs_
+
+        plain_step(0)
+        torch.cuda.synchronize()
         ops.kernel_events = {main_scene.roofline_key: []}
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            Hall, outs = step(0)
-        sync()
-        dt = time.perf_counter() - t0
+        n_roof = max(3, min(args.steps, 10))
+        dt_plain, (Hall, outs) = timed_loop(lambda i: plain_step(0), n_roof, torch.cuda.synchronize)
         events = ops.kernel_events[main_scene.roofline_key]
         # The tile plan of the roofline op (bounding boxes, staging regions, second-launch list) is written by extra workgroups
         # of the refiner_input launch, outside the bracket above.  Three more, untimed, steps with the plan as the op's own launch
@@ -448,7 +472,7 @@ def main():
         ops.FUSE_PLAN = False
         ops.kernel_events = {main_scene.roofline_key: []}
         for i in range(3):
-            step(0)
+            plain_step(0)
         torch.cuda.synchronize()
         events_plan = ops.kernel_events[main_scene.roofline_key]
         ops.FUSE_PLAN = True
@@ -456,7 +480,7 @@ def main():
         # one more, untimed, step with a device sync after every local-correlation call: how many tiles the second launch
         # took and how many cells were redone per tap (both depend on the flows the workload produces)
         ops.kernel_counters = {}
-        step(0)
+        plain_step(0)
         counters = ops.kernel_counters.get(main_scene.roofline_key, [])
         if args.breakdown and rank == 0:
             for name, cs in ops.kernel_counters.items():
@@ -479,33 +503,41 @@ def main():
                 runner2.step(i)
             torch.cuda.synchronize()
             n2 = max(3, min(args.steps, 10))
-            t1 = time.perf_counter()
-            for i in range(n2):
-                runner2.step(0)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
+            dt2, _ = timed_loop(lambda i: runner2.step(0), n2, torch.cuda.synchronize)
             stack_leg = {"value": round(pairs_per_step * n2 / dt2, 2), "unit": "pairs/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
                          "refiner_conv_stack": "reference architecture, random-init, HIP conv_stack kernels, conv_precision='amp' (fp16 maps, "
                                                "fp16 operands, fp32 accumulation: model/network.py:560-562)"}
             del scenes2
-    # secondary figure: the same steps as a stream of batches (sampling + solve of step i under the match of step i + 1)
+    # secondary figure: the same steps on one stream per scene (what `value` was until round 3), from the roofline steps above
     pipe_leg = None
-    if world == 1 and len(scenes) == 1 and not args.pipeline and args.conv_stack == "off" and not args.no_stack_leg:
+    if args.pipeline:
+        pipe_leg = {"value": round(world * pairs_per_step * n_roof / dt_plain, 2), "unit": "pairs/s", "ms_per_step": round(dt_plain / n_roof * 1e3, 3),
+                    "steps": n_roof, "what": "the same steps on ONE stream per scene (sampling + solve of a step not overlapped with the next "
+                                             "step's match; HIP events around the roofline op inside, this rank only): rounds 1-3 reported this as `value`"}
+    # what a hard pair costs: the timed scenes' matches are ~95 % inliers, so OpenCV's confidence bound ends RANSAC after <= 16 hypotheses
+    # and the wide hypothesis / scoring kernels are no-ops.  Same sampled matches with every second correspondence replaced by a random
+    # one: the bound stays at maxIters = 2000 for every pair.
+    worst_leg = None
+    if world == 1 and len(scenes) == 1 and args.conv_stack == "off":
+        from gfnet_amd.estimation import estimate_homographies
+
         with torch.inference_mode():
-            runner_p = SceneRunner(scenes, pipeline=True)
-            for i in range(2):
-                runner_p.step(i)
+            good = outs[0][1].clone()
+            gen = torch.Generator(device=dev).manual_seed(99)
+            bad = torch.rand(good.shape, device=dev, generator=gen) * 2 - 1
+            good[:, ::2] = bad[:, ::2]
+            for _ in range(2):
+                estimate_homographies(good, main_scene.sizes, iters=main_scene.model.ransac_iters, seed=1)
             torch.cuda.synchronize()
-            np_ = max(5, min(args.steps, 20))
-            t1 = time.perf_counter()
-            for i in range(np_):
-                runner_p.step(0)
-            torch.cuda.synchronize()
-            dtp = time.perf_counter() - t1
-        pipe_leg = {"value": round(pairs_per_step * np_ / dtp, 2), "unit": "pairs/s", "ms_per_step": round(dtp / np_ * 1e3, 3), "steps": np_,
-                    "what": "the same steps with two streams per scene: a step's sampling + solve (a third of their time is one-workgroup-"
-                            "per-pair kernels) run under the next step's match; not used for `value` because the overlap takes CUs from the "
-                            "roofline op while it is timed"}
+            nw = 10
+            dtw, Hw = timed_loop(lambda i: estimate_homographies(good, main_scene.sizes, iters=main_scene.model.ransac_iters, seed=1), nw,
+                                 torch.cuda.synchronize)
+            err = [float(np.abs(np.linalg.inv(main_scene.H[k]) @ Hw[k].cpu().numpy() / (np.linalg.inv(main_scene.H[k]) @ Hw[k].cpu().numpy())[2, 2] - np.eye(3)).max())
+                   for k in range(min(4, B))]
+        worst_leg = {"ms_per_batch": round(dtw / nw * 1e3, 3), "pairs": B, "outlier_frac": 0.5,
+                     "what": "RANSAC + DLT + LM of one batch with half of every pair's 5000 correspondences replaced by random ones: 2000 "
+                             "hypotheses scored per pair (the timed steps stop after <= 16); solve time only",
+                     "max_abs_dev_of_H_from_truth_first_pairs": [round(e, 5) for e in err]}
     if in_group:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -564,7 +596,9 @@ def main():
                      "kernel": f"gfn_local_corr_fwd_dt call (tile kernel, its first workgroups finish the tiles the plan left to the second "
                                f"launch; c32, {hs4}x{hs4}, G{G4}, r4, {2 * B} directions).  The tile plan is written by extra workgroups of the "
                                f"preceding refiner_input launch and is NOT inside avg_launch_us / frac; frac_incl_plan times the same op with "
-                               f"the plan as its own launch inside the bracket (3 extra untimed steps)",
+                               f"the plan as its own launch inside the bracket (3 extra untimed steps).  Timed in steps of its own on one "
+                               f"stream per scene, nothing beside it (not in the pipelined timed region, where the previous step's sampling "
+                               f"+ solve share the chip with it)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_incl_plan": round(achieved_plan / HBM_PEAK_GBS, 4),
                      "frac_of_achievable_6p29": round(achieved / HBM_ACHIEVABLE_GBS, 4),
@@ -589,7 +623,10 @@ def main():
     if stack_leg is not None:
         out["with_conv_stacks"] = stack_leg
     if pipe_leg is not None:
-        out["pipelined_steps"] = pipe_leg
+        out["unpipelined_steps"] = pipe_leg
+    if worst_leg is not None:
+        out["solve_worst_case"] = worst_leg
+    out["gc"] = "disabled inside every timed loop"
     if others is not None:
         out["other_workloads"] = others
     if rank == 0:

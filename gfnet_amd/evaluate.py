@@ -75,9 +75,26 @@ def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOL
     mine = pairs[lo:hi]
     errors = np.full(len(mine), np.nan, np.float64)
     elapsed = 0.0
+    # Batches stream through two HIP streams: the matching of batch k + 1 (chip-wide launches) runs while batch k is sampled and
+    # solved on the second stream (a third of that stage is one-workgroup-per-pair kernels -- curve sort, radix select, LM finish --
+    # that leave most of the chip idle), and batch k's 3x3 matrices come back through pinned memory behind an event instead of a
+    # blocking copy.  bench.py times the same arrangement (`config.step_pipeline`).
+    ms, fs = torch.cuda.Stream(), torch.cuda.Stream()
+    pending = None  # (first index, n, ground-truth Hs, sizes, pinned H, event)
+
+    def settle(p):
+        first, n_, Hs_, (w1_, h1_), Hpin, ev = p
+        ev.synchronize()
+        Hp = Hpin.numpy()
+        for k in range(n_):
+            errors[first + k] = corner_error(Hs_[k], Hp[k], w1_, h1_)
+
     i = 0
+    t_loop = time.perf_counter()
+    t_load = 0.0
     while i < len(mine):
         # a batch = consecutive pairs whose images have the same size (test sets are uniform; a change closes the batch)
+        t0 = time.perf_counter()
         ims_a, ims_b, Hs = [], [], []
         while i + len(ims_a) < len(mine) and len(ims_a) < batch_size:
             a, b, hj = mine[i + len(ims_a)]
@@ -90,27 +107,43 @@ def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOL
         n = len(ims_a)
         h1, w1 = ims_a[0].shape[-2:]
         h2, w2 = ims_b[0].shape[-2:]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        A, Bt = torch.stack(ims_a).cuda(non_blocking=True), torch.stack(ims_b).cuda(non_blocking=True)
+        sa, sb = torch.stack(ims_a), torch.stack(ims_b)
+        t_load += time.perf_counter() - t0  # decoding on the host: not part of the reference's per-pair runtime either (estimation.py:56)
         with torch.inference_mode():
-            if hasattr(matcher, "match_batch"):
-                warp, cert = matcher.match_batch(A, Bt)
-                good, _ = sample_batched(matcher, warp, cert, num_samples)
-            else:  # the reference's per-pair surface
-                gs = []
-                for k in range(n):
-                    w_, c_ = matcher.match(A[k:k + 1], Bt[k:k + 1])
-                    gs.append(matcher.sample(w_, c_, num_samples)[0])
-                good = torch.stack(gs)
-            Hp = estimate_homographies(good, (w1, h1, w2, h2), seed=seed + lo + i).cpu().numpy()
-        torch.cuda.synchronize()
-        elapsed += time.perf_counter() - t0
-        for k in range(n):
-            errors[i + k] = corner_error(Hs[k], Hp[k], w1, h1)
+            with torch.cuda.stream(ms):
+                A, Bt = sa.cuda(non_blocking=True), sb.cuda(non_blocking=True)
+                if hasattr(matcher, "match_batch"):
+                    warp, cert = matcher.match_batch(A, Bt)
+                    good = None
+                else:  # the reference's per-pair surface
+                    gs = []
+                    for k in range(n):
+                        w_, c_ = matcher.match(A[k:k + 1], Bt[k:k + 1])
+                        gs.append(matcher.sample(w_, c_, num_samples)[0])
+                    good = torch.stack(gs)
+                    warp = cert = None
+                matched = ms.record_event()
+            with torch.cuda.stream(fs):
+                fs.wait_event(matched)
+                for t in (warp, cert, good):
+                    if t is not None:
+                        t.record_stream(fs)
+                if good is None:
+                    good, _ = sample_batched(matcher, warp, cert, num_samples)
+                Hdev = estimate_homographies(good, (w1, h1, w2, h2), seed=seed + lo + i)
+                Hpin = torch.empty(Hdev.shape, dtype=Hdev.dtype, pin_memory=True)
+                Hpin.copy_(Hdev, non_blocking=True)   # the only device->host copy of a batch
+                solved = fs.record_event()
+        if pending is not None:
+            settle(pending)  # batch k - 1: its matrices have had the whole matching of batch k to arrive
+        pending = (i, n, Hs, (w1, h1), Hpin, solved)
         i += n
         if progress:
             progress(lo + i, len(pairs))
+    if pending is not None:
+        settle(pending)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_loop - t_load
     all_err, total_time = _gather(errors, elapsed, len(pairs), lo, world)
     res = {f"auc@{t}": v for t, v in zip(thresholds, auc(all_err, thresholds))}
     res.update(ace=float(np.mean(all_err)), time=total_time / max(len(pairs), 1), errors=all_err, n=len(pairs))
