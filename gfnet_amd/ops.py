@@ -24,6 +24,11 @@ kernel_events = None
 kernel_counters = None
 # the kernels read fp16 feature maps directly (BASELINE config 5): no widened copy is made
 NATIVE_FP16 = True
+# Large windows (r >= 5 on 64-channel maps) multiply on the matrix core with split-bf16 operands by default: every product is exact to
+# 2^-17 relative, so a correlation value is within 2^-17 * sum_c |f0_c * f1_c| / sqrt(C) of the fp32 result (a few 1e-6 on unit-scale
+# features, but proportional to the operands' magnitude, not to the result's: strongly cancelling sums lose relative accuracy).
+# True keeps every radius on the fp32 FMA kernels (C-ABI variant 4), bit-identical to the round-1 kernel.
+LOCAL_CORR_FP32 = False
 # refiner_input writes the tile plan of the local correlation that follows it from extra workgroups of its own launch.  bench.py
 # switches this off for a few untimed steps so that the plan becomes the correlation call's own first launch and lands inside its
 # event bracket (`roofline.frac_incl_plan`).
@@ -132,7 +137,8 @@ def refiner_input(num_grid, x, y, flow, disp_w, disp_b, local_radius, scale_fact
         out = d[:, 2 * C + Dd:]
         name = f"local_corr_c{C}_h{Hs}_g{G}_r{r}"
         check(_timed(name, lambda: _L().gfn_local_corr_fwd_dt(ptr(d), CH * G * G, ptr(y), ptr(x) if symmetric else None, dtx, ptr(fl),
-                                                              c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws, 8 if plans else 0,
+                                                              c_vp(out.data_ptr()), CH * G * G, B, C, G, Hs, Ws, r, 0, Hs, Ws,
+                                                              (8 if plans else 0) | (4 if LOCAL_CORR_FP32 and r >= 5 else 0),
                                                               ptr(scr), nscr, st)), "gfn_local_corr_fwd")
         if kernel_counters is not None:
             hdr = scr[:8].cpu()  # synchronises; header layout: csrc/local_corr.hip kTodoHdr

@@ -77,9 +77,11 @@ def _forward(featuremap_size, feature0, feature1, local_radius, num_grid, paddin
     hh, ww = h, w
     for level in range(int(num_level)):
         o = res[:, level * K1:(level + 1) * K1]
+        from .. import ops  # (LOCAL_CORR_FP32: fp32 FMA arithmetic at every radius instead of the matrix-core kernel for r >= 5)
+        variant = 4 if (int(_variant) == 0 and ops.LOCAL_CORR_FP32) else int(_variant)
         _lib.check(L.gfn_local_corr_fwd_dt(_lib.ptr(f0), f0_bs, _lib.ptr(f1), None, f1_dt, _lib.ptr(fl), _lib.c_vp(o.data_ptr()),
                                            out_bs, B, c, G, hh, ww, r, 1 if grid_based_correlation else 0, h, w,
-                                           int(_variant), _lib.ptr(scr), nscr, st), "gfn_local_corr_fwd")
+                                           variant, _lib.ptr(scr), nscr, st), "gfn_local_corr_fwd")
         if level + 1 < num_level:
             if f1_dt != _lib.GFN_F32:  # pooled levels (unused by GFNet) are built in fp32
                 f1, f1_dt = _lib.f32c(f1), _lib.GFN_F32

@@ -349,3 +349,35 @@ def test_local_correlation_fp16_features():
     assert out.dtype == torch.float16
     want = oracle.local_correlation((B, c, h, w), f0.astype(np.float32), f1.astype(np.float32), r, G, flow=flow)
     assert_close(out.float().cpu().numpy(), want, 2e-3, "fp16 features")  # one fp16 rounding of the result
+
+
+@pytest.mark.parametrize("hs,G,r", [(56, 32, 6), (32, 32, 7)])
+def test_large_windows_error_follows_the_operands_not_the_result_and_the_fp32_switch(hs, G, r):
+    """the matrix-core path of r >= 5 splits operands into bf16 pairs, so a value is within 2^-17 * sum_c |f0_c f1_c| / sqrt(C)
+    of the fp32 result -- a bound in the operands' magnitude.  Features of magnitude ~100 whose channel sums cancel (f0 = a common
+    pairs of opposite sign against nearly equal f1 channels) make |result| << sum |products|: the 1e-4 * max(1, |ref|) rule of the unit-scale tests does
+    not apply there, the operand bound does, and ops.LOCAL_CORR_FP32 (C-ABI variant 4) gives the fp32 FMA kernel's bits."""
+    from gfnet_amd import ops
+
+    B, c = 2, 64
+    f0 = synth.lattice_normalish((B, c, G, G), 951 + r) * np.float32(100.0)
+    f0[:, 1::2] = -f0[:, 0::2]                            # channel pairs of opposite sign ...
+    f1 = synth.lattice_normalish((B, c, hs, hs), 952 + r) * np.float32(100.0)
+    f1[:, 1::2] = f1[:, 0::2] * np.float32(1.0 + 1e-3)   # ... against nearly equal ones: every pair's two products cancel to 1e-3
+    flow = synth.homography_flow(B, G, 953 + r)
+    ref = oracle.local_correlation((B, c, hs, hs), f0, f1, r, G, flow=flow)
+    mag = oracle.local_correlation((B, c, hs, hs), np.abs(f0), np.abs(f1), r, G, flow=flow)   # sum_c |f0_c| * bilinear(|f1_c|) / sqrt(C)
+    assert np.abs(ref).max() < 0.05 * mag.max()          # the sums do cancel
+    default = run(f0, f1, flow, r, G)
+    fp32 = run(f0, f1, flow, r, G, _variant=2)
+    # the fp32 FMA kernel against the float64-accumulating oracle: a few ulp of the partial sums
+    assert np.all(np.abs(fp32 - ref) <= 2.0 ** -19 * mag + 1e-6)
+    # the split-bf16 products: 2^-17 of the operand magnitude (plus the fp32 summation error above)
+    assert np.all(np.abs(default - ref) <= 2.0 ** -16 * mag + 1e-6)
+    assert not np.array_equal(default, fp32)
+    ops.LOCAL_CORR_FP32 = True
+    try:
+        switched = run(f0, f1, flow, r, G)
+    finally:
+        ops.LOCAL_CORR_FP32 = False
+    np.testing.assert_array_equal(switched, fp32)
