@@ -136,11 +136,13 @@ def parse_args():
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", help="force the two-stream arrangement (see --no-pipeline)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="one stream per scene inside the timed region (default: two -- a step's sampling + solve run on a second stream under "
                          "the next step's match, the way gfnet_amd.evaluate streams batches; the roofline op is timed in separate, "
                          "un-overlapped steps either way, and the default line reports the one-stream rate as `unpipelined_steps`)")
-    ap.set_defaults(pipeline=True)
+    ap.set_defaults(pipeline=None)  # None: two streams for one-scene workloads, one stream per scene for the three-scene pyramid workload
+                                    # (six streams slow it down: 6.8 k -> 5.5 k pairs/s, round 3)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="take the self-launch path (parent starts the rank processes, relays rank 0's line) also for --gpus 1: the "
@@ -408,6 +410,8 @@ def main():
             dist.barrier()
     dev = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
+    if args.pipeline is None:
+        args.pipeline = len(wl["sizes"]) == 1
     B = args.pairs_per_gpu or wl["pairs"]
     dtype = torch.float16 if wl["dtype"] == "fp16" else torch.float32
 
