@@ -203,7 +203,9 @@ class Scene:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, stream=self._gstream):
             self._graph_out = self.step(seed)
-        torch.cuda.current_stream().wait_stream(self._gstream)
+        # (No wait_stream on the capture stream here: nothing has run yet, and on ROCm 7.2 an event recorded on the stream right
+        # behind the end of its capture, waited for by the default stream, made a LATER replay fault once the default stream had
+        # touched other tensors -- tools/dbg_graph.py, modes eager_inl / eager_inl_wait.)
         return self._graph_out
 
     def replay(self):

@@ -269,9 +269,9 @@ def test_a_scene_step_replayed_from_a_hipgraph_equals_the_eager_step():
     """Round 4: a whole step (both passes of the coarse-to-fine loop, sampling, solve: ~300 launches) captured once into a hipGraph
     (Scene.capture: torch.cuda.graph around the C-ABI launches, which allocate nothing and run on the caller's stream) and replayed:
     H and the sampled matches are bit-identical to the eager step with the same seeds, replay after replay.
-    (The comparisons run on the capture stream: on ROCm 7.2 default-stream work on tensors of the eager steps BETWEEN two replays of
-    the full-step graph ends the next replay with a memory fault -- reproduced with tools/dbg_graph.py, not with the matching or the
-    sampling + solve captured alone, cause not found)"""
+    (The comparisons run on the capture stream: on ROCm 7.2 default-stream work that reads a replay's outputs together with tensors of the
+    eager steps, between two replays of the full-step graph, ends a later replay with a memory fault -- reproduced with
+    tools/dbg_graph.py, cause not found)"""
     from gfnet_amd._synthetic import Scene
 
     dev = torch.device("cuda", torch.cuda.current_device())
