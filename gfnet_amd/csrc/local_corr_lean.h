@@ -33,7 +33,12 @@ template <int R> __device__ __forceinline__ bool mm_region_fits_rt(int w, int h,
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
-constexpr int kPlanInts = 8;  // per tile: region A x0, y0, (h << 16) | w, flags; region B x0, y0, (h << 16) | w, spare
+constexpr int kPlanInts = 16;  // per tile: region A x0, y0, (h << 16) | w, flags; region B x0, y0, (h << 16) | w, geometry of A;
+                               // geometry of B, direction b, row0 | col0 << 16, spare ...  (geometry = pitch | quads per row << 8 | items << 16:
+                               // round 4 -- the tile kernel no longer derives the regions' pitch and item count (region_fits) and the tile's
+                               // direction / position (two integer divisions) in front of its first load: ~120 of a wave's ~1 550 instructions)
+constexpr int kPlanV4 = kPlanInts / 4;
+__device__ __forceinline__ int plan_geometry(const RowPlan &u) { return u.pitch | (u.nq << 8) | (u.nitems << 16); }
 constexpr int kPlanInterior = 1, kPlanSecond = 2, kPlanHalves = 4;
 // flags: kPlanInterior -- no staged pixel lies outside the image; kPlanSecond -- the tile is on the second launch's list;
 // kPlanHalves -- the windows of the whole tile do not fit the stage, those of its two 4 x 8-cell halves do: region A serves
@@ -197,8 +202,8 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 if (w == 0 || h == 0) { x0 = 0; y0 = 0; w = 0; h = 0; }
                 const bool fits = mm_ok && mm_region_fits_rt<R>(w, h, p.C);
                 const int flags = (all_in ? kPlanInterior : 0) | (fits ? 0 : kPlanSecond);
-                reinterpret_cast<int4 *>(p.plan)[2 * wid] = make_int4(x0, y0, (h << 16) | w, flags);
-                reinterpret_cast<int4 *>(p.plan)[2 * wid + 1] = make_int4(0, 0, 0, 0);
+                reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid] = make_int4(x0, y0, (h << 16) | w, flags);
+                reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid + 1] = make_int4(0, 0, 0, 0);
                 if (!fits) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;
                 continue;
             }
@@ -214,8 +219,12 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
             int4 pl0, pl1;
             pl0.x = ua.x0; pl0.y = ua.y0; pl0.z = (ua.h << 16) | ua.w; pl0.w = flags;
             pl1.x = ub.x0; pl1.y = ub.y0; pl1.z = (ub.h << 16) | ub.w; pl1.w = 0;
-            reinterpret_cast<int4 *>(p.plan)[2 * wid] = pl0;
-            reinterpret_cast<int4 *>(p.plan)[2 * wid + 1] = pl1;
+            pl1.w = plan_geometry(ua);
+            const int wb = (int)(wid / (unsigned)tiles), wt = (int)(wid - (unsigned)wb * (unsigned)tiles);
+            const int wty = wt / p.tiles_x, wtx = wt - wty * p.tiles_x;
+            reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid] = pl0;
+            reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid + 1] = pl1;
+            reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid + 2] = make_int4(plan_geometry(ub), wb, (wty * 4) | ((wtx * kTileW) << 16), 0);
             if (flags & kPlanSecond) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;  // strong magnification / scattered flow: second launch
             else if ((flags & kPlanHalves) && (wid & 15u) == 0) atomicAdd(p.todo + 6, 16);  // informational, sampled: an atomic per tile
                                                                                             // on one word costs ~11 ns each
@@ -263,8 +272,8 @@ struct DivPW {
 // HALVES: the tile is staged as two 4 x 8-cell halves, one after the other (region uA for cells 0-31 = round 0, uB for cells
 // 32-63 = round 1); otherwise uA serves both rounds.
 template <int R, int NCH, bool CHECK, bool HALVES, typename FT>
-__device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, unsigned wid, int tid,
-                                          int lane, int wave) {
+__device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, int b, int row0, int col0,
+                                          int tid, int lane, int wave) {
     constexpr int ROUNDS = 2;
     constexpr int C = 16 * NCH;
     constexpr int kStageBytes = Lean<R>::kStage;  // shadows the round-1 constant
@@ -289,10 +298,6 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + kTabBytes);  // [NC][C + 4]: the tile's f0, cell-major
 
     const int G = p.G, H = p.H, W = p.W;
-    const int tiles = p.tiles_x * p.tiles_y;
-    const int b = wid / tiles, tile = wid - b * tiles;
-    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const int row0 = ty * 4, col0 = tx * kTileW;
     const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;
     const unsigned GG4 = (unsigned)(G * G) * 4u;  // bytes of a (G,G) plane
 #ifdef GFN_ABLATE
@@ -630,25 +635,33 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
     // have in the vector-memory pipeline
     typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x4s __attribute__((ext_vector_type(4)));
     i32x8 pl;
+    i32x4s pg;
     {
         const int *pp = p.plan + (size_t)wid * kPlanInts;
-        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pl) : "s"(pp) : "memory");
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pl), "=&s"(pg) : "s"(pp) : "memory");
     }
     const int flags = pl[3];
     if (flags & kPlanSecond) return;  // the plan launch has put this tile on the second launch's list (block-uniform)
     RowPlan uA, uB;
     uA.x0 = pl[0]; uA.y0 = pl[1]; uA.w = pl[2] & 0xffff; uA.h = pl[2] >> 16;
     uB.x0 = pl[4]; uB.y0 = pl[5]; uB.w = pl[6] & 0xffff; uB.h = pl[6] >> 16;
-    if (ABL(p, 64)) { uA.h = min(uA.h, 7); uB.h = min(uB.h, 7); }  // timing experiment: what a row ring would stage per tile
-    (void)region_fits<R>(uA);         // pitch, quads per row, rows per item, items (the plan launch checked that they fit)
-    (void)region_fits<R>(uB);
+    // pitch, quads per row and items as the plan launch worked them out (region_fits, checked there)
+    uA.pitch = pl[7] & 0xff; uA.nq = (pl[7] >> 8) & 0xff; uA.nitems = pl[7] >> 16;
+    uB.pitch = pg[0] & 0xff; uB.nq = (pg[0] >> 8) & 0xff; uB.nitems = pg[0] >> 16;
+    if (ABL(p, 64)) {  // timing experiment: what a row ring would stage per tile
+        uA.h = min(uA.h, 7); uB.h = min(uB.h, 7);
+        (void)region_fits<R>(uA);
+        (void)region_fits<R>(uB);
+    }
+    const int b = pg[1], row0 = pg[2] & 0xffff, col0 = pg[2] >> 16;
     const bool interior = (flags & kPlanInterior) != 0;
     if (flags & kPlanHalves) {
-        if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, wid, tid, lane, wave);
-        else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, wid, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     } else {
-        if (interior) lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, wid, tid, lane, wave);
-        else lean_tile<R, NCH, true, false, FT>(p, smem, uA, uB, wid, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        else lean_tile<R, NCH, true, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     }
 }

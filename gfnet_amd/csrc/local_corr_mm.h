@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
     F cur;
     {
         const unsigned wid = gfn::xcd_remap(v, total);
-        mm_fetch<R, C, FT>(p, cur, wid, plans[2 * wid], lane0, wave0);
+        mm_fetch<R, C, FT>(p, cur, wid, plans[kPlanV4 * wid], lane0, wave0);
     }
     for (;;) {
         // the lane and wave numbers are made opaque per iteration: the compiler otherwise hoists every lane-derived constant of the
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kMmThreads, 4) void local_corr_mm1_kernel(LcParams 
         const unsigned vn = v + gridDim.x;
         const bool has_next = vn < total;
         const unsigned wid_next = has_next ? gfn::xcd_remap(vn, total) : 0u;
-        const int4 pl_next = plans[2 * wid_next];   // consumed behind the first barrier: a whole staging phase to arrive
+        const int4 pl_next = plans[kPlanV4 * wid_next];   // consumed behind the first barrier: a whole staging phase to arrive
         F nxt;
         nxt.pflags = kPlanSecond;
         const MmTile ct = mm_tile_scalars<R, C>(p, cur.wid, cur.px0, cur.py0, cur.phw, cur.pflags);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kMwThreads, 2) void local_corr_mw_kernel(LcParams p
     const unsigned GG4 = (unsigned)(G * G) * 4u;
     const unsigned wid = gfn::xcd_remap(blockIdx.x, gridDim.x);
     // the plan came through a vector load of a uniform address: say so (scalar offsets of the buffer loads, uniform branches)
-    const int4 pl = reinterpret_cast<const int4 *>(p.plan)[2 * wid];
+    const int4 pl = reinterpret_cast<const int4 *>(p.plan)[kPlanV4 * wid];
     const int pflags = __builtin_amdgcn_readfirstlane(pl.w);
     if (pflags & kPlanSecond) return;  // on the second launch's list
     MmRegion u;
