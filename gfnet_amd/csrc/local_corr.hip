@@ -1217,8 +1217,10 @@ int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s, bool keep
     const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
-    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
-    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), dim3(q_blocks + p_blocks, (unsigned)q.B), dim3(256), 0, s, q, p, q_blocks);
+    const int banded = gfn_ri::ri_bands(q.B, q.Bh, q_blocks) ? 1 : 0;  // symmetric batches: XCD-banded order of the refiner-input blocks
+    const dim3 grid = banded ? dim3(gfn_ri::ri_banded_blocks(q.B, q_blocks) + p_blocks * (unsigned)q.B) : dim3(q_blocks + p_blocks, (unsigned)q.B);
+    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
+    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
     return gfn::check_launch("refiner_input_plan_kernel");
 }
 }  // namespace

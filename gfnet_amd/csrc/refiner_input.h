@@ -120,6 +120,29 @@ __device__ __forceinline__ int ri_direction(int B, int Bh, unsigned by) {
     return Bh < B ? ((by & 1) ? (int)(by >> 1) + Bh : (int)(by >> 1)) : (int)by;
 }
 
+// Round 4, symmetric batches: a 1-D grid in XCD-BANDED order.  Blocks are dealt round-robin over the 8 XCDs (id & 7 = the XCD,
+// id >> 3 = the block's place in that XCD's queue; a speed assumption only), and every map is read twice -- regularly by one
+// direction of its pair (grid_feature), along the flow by the other (x_hat).  An XCD takes ONE band (an eighth of the cell blocks,
+// consecutive rows) of BOTH directions of a pair, alternating between them, so that the band's rows of the two maps (a few MB:
+// they stay in its 4 MB L2 for the band's duration) serve the second reader wherever the flow keeps it inside the band.  The
+// per-direction order (blockIdx.y = direction, every XCD all over the map) fetched every map 2.2x through L2; measured on the
+// bench's scene: 399 -> 332 us (G 320), 248 -> 211 (G 256), 121 -> 108 (G 128, with the plan).  Bands are floor(k q / 8) ..
+// floor((k + 1) q / 8): when 8 does not divide q they differ by one block, every XCD gets ceil(q / 8) slots per direction (the
+// spare slot of a short band returns at once) and the band an XCD takes rotates with the pair so that the long bands go round.
+__device__ __forceinline__ unsigned ri_band_slots(unsigned q_blocks) { return (q_blocks + 7u) >> 3; }
+__device__ __forceinline__ bool ri_banded(unsigned id, unsigned q_blocks, int Bh, int &b, unsigned &x) {
+    const unsigned slots = ri_band_slots(q_blocks), xcd = id & 7u, s = id >> 3;
+    const unsigned per_pair = 2u * slots;
+    const unsigned p = s / per_pair, t = s - p * per_pair;
+    const unsigned band = (xcd + p) & 7u;
+    const unsigned lo = (band * q_blocks) >> 3, hi = ((band + 1u) * q_blocks) >> 3;
+    x = lo + (t >> 1);
+    b = (t & 1u) ? (int)p + Bh : (int)p;
+    return x < hi;
+}
+inline bool ri_bands(int B, int Bh, unsigned q_blocks) { return Bh < B && q_blocks >= 8; }
+inline unsigned ri_banded_blocks(int B, unsigned q_blocks) { return 8u * ((q_blocks + 7u) >> 3) * (unsigned)B; }
+
 struct RiArgs {
     const void *fa, *fb;   // feature maps of the two images (Bh, C, Hs, Ws), fp32 or fp16
     const float *flow, *dw, *db;
