@@ -334,21 +334,36 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
             # every scene's step captured once into a hipGraph on a stream of its own, a timed step = one replay per scene: the
             # host issues 3 launches per step instead of ~300 (Scene.capture).  Eager stays the fallback: never re-exec'ed, and a
             # capture that fails only costs this leg its graph numbers.
+            # With several scenes the largest one's chain of kernels sets the step: it gets the two-stage form (match and finish
+            # captured apart, its sampling + solve under its next step's matching: Scene.capture_pipelined); two-stage graphs for
+            # every scene put more streams on the chip than they find idle CUs for (pyr-fp16: 6.7 k against 8.2 k pairs/s).
             try:
-                for sc in scenes:
-                    sc.capture(0)
+                longest = max(scenes, key=lambda sc: sc.size)
+                # (the eager steps' streams again, one new one for the second stage: four streams whose first uses were consecutive
+                # sit on four different hardware queues -- Scene.capture)
+                for sc, pair in zip(scenes, runner.streams):
+                    if sc is longest:
+                        sc.capture_pipelined(0, streams=(pair[0], torch.cuda.Stream()) if pair is not None else None)
+                    else:
+                        sc.capture(0, stream=pair[0] if pair is not None else None)
                 torch.cuda.synchronize()
-                for _ in range(2):
+
+                def replay_all():
                     for sc in scenes:
-                        sc.replay()
+                        if sc is longest:
+                            sc.replay_pipelined()
+                        else:
+                            sc.replay()
+
+                for _ in range(4):
+                    replay_all()
                 torch.cuda.synchronize()
                 gc.collect()
                 gc.disable()
                 try:
                     t0 = time.perf_counter()
                     for i in range(steps):
-                        for sc in scenes:
-                            sc.replay()
+                        replay_all()
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                 finally:
@@ -364,7 +379,9 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     nbytes = algorithmic_bytes_local_corr(2 * wl["pairs"], 32, side_of("4", S0), main_scene.grids[2], 4, fbytes)
     out = {"value": round(pairs * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "pairs_per_step": pairs, "workload": wl["label"],
-           "mode": ("hipGraph replay: one captured step per scene and stream (seeds of the capture)" if graphs else "eager launches"),
+           "mode": (("hipGraph replay (seeds of the capture): " + ("one captured step per scene and stream; the largest scene as " if len(scenes) > 1 else "") +
+                     "two graphs on two streams (match | sampling + solve), a step's second stage under the next step's first")
+                    if graphs else "eager launches"),
            "eager": {"value": round(pairs * steps / dt_eager, 2), "ms_per_step": round(dt_eager / steps * 1e3, 3)},
            "roofline_op": f"scale-4 local correlation, c32, {side_of('4', S0)}x{side_of('4', S0)}, G{main_scene.grids[2]}, r4, {2 * wl['pairs']} directions",
            "roofline_timed_in": "the eager steps (HIP events around the C-ABI call; with several scenes their streams run concurrently)",

@@ -188,13 +188,16 @@ class Scene:
     # (torch.cuda.graph: tensors the Python layer creates inside the capture live in the graph's private pool) and replays with a
     # single launch.  Seeds are kernel arguments: a replay repeats the draws of its capture (re-capture, or run eagerly, for fresh
     # draws per batch); timing hooks (ops.kernel_events / kernel_counters) must be off while capturing.
-    def capture(self, seed=0, warmup=2):
-        """Capture step(seed) on a stream of its own; returns the static output tensors (H, good matches) every replay() refills."""
+    def capture(self, seed=0, warmup=2, stream=None):
+        """Capture step(seed) on `stream` (default: a new one); returns the static output tensors (H, good matches) every replay()
+        refills.  (The HIP runtime deals a process's streams onto 4 hardware queues in the order of their first use -- rocprofv3's
+        Queue_Id --, and two streams on one queue run one after the other: scenes that replay side by side want streams whose
+        first uses were consecutive, which is why the stream can be handed in.)"""
         from gfnet_amd import ops
 
         if ops.kernel_events is not None or ops.kernel_counters is not None:
             raise RuntimeError("Scene.capture: switch ops.kernel_events / ops.kernel_counters off first (they record events / synchronise)")
-        self._gstream = torch.cuda.Stream()
+        self._gstream = stream if stream is not None else torch.cuda.Stream()
         self._gstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._gstream):
             for _ in range(warmup):  # lazy module state, the stream's scratch buffers, the allocator's pools
@@ -213,4 +216,58 @@ class Scene:
         with torch.cuda.stream(self._gstream):
             self._graph.replay()
         return self._graph_out
+
+    # The two-stream arrangement of bench.py's SceneRunner as graphs: match and finish captured APART on a stream each, twice each
+    # (a match graph's outputs are static buffers: the second copy lets step i + 1's match run while step i's finish still reads
+    # the first), events between the replays.  A step's sampling + solve -- a third of its time one-workgroup-per-pair kernels --
+    # then runs under the next step's matching, as in the eager pipeline, at four launches per step.
+    def capture_pipelined(self, seed=0, warmup=2, streams=None):
+        from gfnet_amd import ops
+
+        if ops.kernel_events is not None or ops.kernel_counters is not None:
+            raise RuntimeError("Scene.capture_pipelined: switch ops.kernel_events / ops.kernel_counters off first")
+        cur = torch.cuda.current_stream()
+        self._ms, self._fs = streams if streams is not None else (torch.cuda.Stream(), torch.cuda.Stream())
+        self._ms.wait_stream(cur)
+        self._fs.wait_stream(cur)
+        with torch.cuda.stream(self._ms):
+            for _ in range(warmup):
+                warp, cert = self.match()
+        self._ms.synchronize()
+        with torch.cuda.stream(self._fs):
+            for _ in range(warmup):
+                self.finish(warp, cert, seed)
+        self._fs.synchronize()
+        self._mgraph, self._fgraph, self._mout, self._fout = [], [], [], []
+        for _ in range(2):
+            mg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(mg, stream=self._ms):
+                mout = self.match()
+            torch.cuda.synchronize()
+            fg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fg, stream=self._fs):
+                fout = self.finish(mout[0], mout[1], seed)
+            torch.cuda.synchronize()
+            self._mgraph.append(mg)
+            self._fgraph.append(fg)
+            self._mout.append(mout)
+            self._fout.append(fout)
+        self._turn, self._fdone = 0, [None, None]
+        return self._fout
+
+    def replay_pipelined(self):
+        """One step through the two captured stages; returns this step's static outputs (H, good matches) and the event that says
+        they are complete (they are overwritten by the replay after next)."""
+        k = self._turn
+        self._turn ^= 1
+        if self._fdone[k] is not None:
+            self._ms.wait_event(self._fdone[k])  # the finish of two steps ago has read this match graph's outputs
+        with torch.cuda.stream(self._ms):
+            self._mgraph[k].replay()
+        mdone = self._ms.record_event()
+        self._fs.wait_event(mdone)
+        with torch.cuda.stream(self._fs):
+            self._fgraph[k].replay()
+        self._fdone[k] = self._fs.record_event()
+        return self._fout[k], self._fdone[k]
 

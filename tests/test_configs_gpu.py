@@ -291,3 +291,32 @@ def test_a_scene_step_replayed_from_a_hipgraph_equals_the_eager_step():
                 same = bool(torch.equal(Hg, He)) and bool(torch.equal(gg, ge))
                 finite = bool(torch.isfinite(Hg).all())
             assert same and finite
+
+
+def test_the_two_stage_hipgraph_replay_equals_the_eager_steps():
+    """Round 4: match and finish captured apart, twice each (Scene.capture_pipelined: a step's sampling + solve replays under the next
+    step's matching; the two copies of a stage alternate so that a match never overwrites what a finish still reads).  Copy 0 holds the
+    sampler draws of the third eager step with the same generator seed, copy 1 those of the fourth; six replays in a row return, in
+    turn, exactly those two eager results.  (Comparisons on the finish stream, as in the one-graph test above.)"""
+    from gfnet_amd._synthetic import Scene
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with torch.inference_mode(False):
+        sc = Scene(224, 2, [1] * 5, torch.float16, "off", dev, 0)
+    with torch.inference_mode():
+        torch.manual_seed(11)
+        eager = []
+        for _ in range(4):
+            He, ge = sc.step(5)
+            eager.append((He.clone(), ge.clone()))
+        torch.cuda.synchronize()
+        torch.manual_seed(11)  # capture_pipelined: two warm-up finishes, then the two captured copies
+        sc.capture_pipelined(5, warmup=2)
+        for rep in range(6):
+            (Hg, gg), done = sc.replay_pipelined()
+            He, ge = eager[2 + (rep & 1)]
+            with torch.cuda.stream(sc._fs):
+                same = bool(torch.equal(Hg, He)) and bool(torch.equal(gg, ge))
+                finite = bool(torch.isfinite(Hg).all())
+            assert same and finite, f"replay {rep}"
+        torch.cuda.synchronize()
