@@ -79,7 +79,7 @@ def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOL
     # solved on the second stream (a third of that stage is one-workgroup-per-pair kernels -- curve sort, radix select, LM finish --
     # that leave most of the chip idle), and batch k's 3x3 matrices come back through pinned memory behind an event instead of a
     # blocking copy.  bench.py times the same arrangement (`config.step_pipeline`).
-    ms, fs = torch.cuda.Stream(), torch.cuda.Stream()
+    ms, fs = parallel.concurrent_streams(2)  # two streams on different hardware queues (parallel.py)
     pending = None  # (first index, n, ground-truth Hs, sizes, pinned H, event)
 
     def settle(p):

@@ -52,3 +52,58 @@ def gather_homographies(H_local, counts=None):
     dist.all_gather_into_tensor(out, buf.contiguous())
     out = out.view(world, nmax, 3, 3)
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+# ---- streams that really run side by side -------------------------------------------------------------------------------------------
+# The HIP runtime deals a process's streams onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES) as they are first used, not
+# one to one: on ROCm 7.2 the fourth and fifth stream of a process share a queue, and two streams on one queue run one after the other
+# whatever the events between them say (rocprofv3's Queue_Id).  The two-stream pipelines (match | sampling + solve) and the
+# scene-per-stream steps therefore take their streams from here: a process-wide pool whose members were TESTED to overlap -- two
+# one-workgroup spin kernels, one per stream, take as long as one when the queues differ and as long as two when they are shared.
+_stream_pool = {}
+
+
+def _overlap(a, b, cycles=400_000):
+    """True when work on streams a and b runs concurrently (a one-workgroup spin on each: ~0.2 ms alone)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        ev[0].record()
+        torch.cuda._sleep(cycles)
+        ev[1].record()
+    torch.cuda.synchronize()
+    alone = ev[0].elapsed_time(ev[1])
+    start = torch.cuda.Event()
+    start.record()          # both streams wait for the same point, then spin
+    a.wait_event(start)
+    b.wait_event(start)
+    with torch.cuda.stream(a):
+        ev[0].record()
+        torch.cuda._sleep(cycles)
+        ev[1].record()
+    with torch.cuda.stream(b):
+        ev[2].record()
+        torch.cuda._sleep(cycles)
+        ev[3].record()
+    torch.cuda.synchronize()
+    both = max(ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), ev[0].elapsed_time(ev[3]))
+    return both < 1.5 * alone
+
+
+def concurrent_streams(n, device=None, tries=16):
+    """n HIP streams of the current device that pairwise run concurrently (see above); the same streams on every call (a pool that
+    grows as needed).  Falls back to plain new streams for members it cannot find in `tries` candidates (more streams than
+    hardware queues): the work is still correct, only less overlapped."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    pool = _stream_pool.setdefault(dev, [])
+    with torch.cuda.device(dev):
+        rejected = 0
+        while len(pool) < n and rejected < tries:
+            cand = torch.cuda.Stream()
+            if all(_overlap(cand, s) for s in pool):
+                pool.append(cand)
+            else:
+                rejected += 1
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream())
+    return pool[:n]

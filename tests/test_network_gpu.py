@@ -292,3 +292,19 @@ def test_scratch_is_dropped_after_a_failed_call_and_streams_do_not_share_it():
     keys = [k for k in _lib._scratch if k[2] in (s1.cuda_stream, s2.cuda_stream)]
     assert len(keys) == 2 and _lib._scratch[keys[0]].data_ptr() != _lib._scratch[keys[1]].data_ptr()
     assert torch.equal(a, ref) and torch.equal(b2, ref)
+
+
+def test_pooled_streams_run_side_by_side():
+    """Round 4: the HIP runtime deals streams onto 4 hardware queues, not one to one, and streams that share a queue serialise
+    (rocprofv3 Queue_Id; tools/probe_streams.py).  parallel.concurrent_streams hands out streams it has tested pairwise with two
+    one-workgroup spin kernels; the same objects on every call."""
+    from gfnet_amd import parallel
+
+    pool = parallel.concurrent_streams(3)
+    assert len(pool) == 3 and len({s.cuda_stream for s in pool}) == 3
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert parallel._overlap(pool[i], pool[j]), (i, j)
+    again = parallel.concurrent_streams(2)
+    assert again[0] is pool[0] and again[1] is pool[1]
+    assert len(parallel.concurrent_streams(9)) == 9  # more than the hardware queues: still nine usable streams
