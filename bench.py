@@ -526,6 +526,11 @@ def main():
         others = None
         if args.workload == "448b32" and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
             others = {k: secondary_workload(k, "off", dev, rank, 8) for k in ("672b16", "pyr-fp16")}
+        # the three-scene workload as the main workload: `value` above is eager (fresh seeds every step); the same workload driven by
+        # hipGraph replays (largest scene in two stages) is reported next to it, measured exactly like the default line's leg
+        graph_leg = None
+        if len(wl["sizes"]) > 1 and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
+            graph_leg = secondary_workload(args.workload, "off", dev, rank, max(8, min(args.steps, 20)))
         # secondary figure: the same step with the refiners' real conv stacks (reference architecture, random-init)
         # in the class the reference runs them in on a GPU -- `value` above replaces them by a one-op stand-in
         stack_leg = None
@@ -663,6 +668,8 @@ def main():
     out["gc"] = "disabled inside every timed loop"
     if others is not None:
         out["other_workloads"] = others
+    if graph_leg is not None:
+        out["graph_replay"] = graph_leg
     if rank == 0:
         print(json.dumps(out), flush=True)
     if in_group:
