@@ -350,7 +350,10 @@ __device__ __forceinline__ void stage_rest(float4 *s4, const FT *f1c, int H, int
 //   SECOND = true : second launch -- an irregular tile is cut into 4 x 8 sub-tiles, each staged on
 //                   its own (half the footprint along the grid row, so twice the magnification
 //                   fits); a sub-tile that still does not fit falls through to the gather variant.
-template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND, typename FT, int STAGE = 68 * 1024>
+//   QOK: the r >= 5 staging may use the 16-byte quad loads (fp16 maps: only with an even width -- 4-byte aligned 8-byte quads; the
+//        host picks the instantiation.  As a run-time flag both staging forms' registers were live at once: the fp16 kernels spilled
+//        16-39 registers at 128)
+template <int R, int ROUNDS, bool STAGED, int TW, bool SECOND, typename FT, int STAGE = 68 * 1024, bool QOK = true>
 __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0, int col0, int rows, unsigned wid,
                                              unsigned char *smem) {
     constexpr int kStageBytes = STAGE;       // shadow the file-level defaults: the lean kernel runs this path inside its own,
@@ -495,8 +498,8 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     // vector-memory issue path.  A row is then whole quads (the last one may hang over the region's right edge: its pixels land in
     // pad slots nobody reads; past the tensor the descriptor returns zeros).  fp16 maps need even x0 and even rows (4-byte aligned
     // 8-byte quads); odd-width fp16 maps keep the narrow loads.
-    constexpr bool kQuads = STAGED && R >= 5;
-    const bool quads = kQuads && (sizeof(FT) == 4 || (W & 1) == 0);  // fp32 maps: a compile-time constant (no branch around the loads)
+    constexpr bool kQuads = STAGED && R >= 5 && QOK;
+    constexpr bool quads = kQuads;  // a compile-time constant: no branch around the loads, one staging form's registers
     if (quads && sizeof(FT) == 2 && (u.x0 & 1)) { u.x0 -= 1; u.w += 1; }
     const int w4 = quads ? ((u.w + 3) & ~3) : u.w;
     u.pitch = w4 + ((PW - w4) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
@@ -510,7 +513,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
         } else {
             __syncthreads();
             if (ABL(p, 1024)) return;
-            process_tile<R, ROUNDS, false, TW, true, FT, STAGE>(p, b, row0, col0, rows, wid, smem);  // gather from L2
+            process_tile<R, ROUNDS, false, TW, true, FT, STAGE, QOK>(p, b, row0, col0, rows, wid, smem);  // gather from L2
         }
         return;
     }
@@ -790,7 +793,7 @@ __device__ __forceinline__ void process_tile(const LcParams &p, int b, int row0,
     }
 }
 
-template <int R, int ROUNDS, typename FT>
+template <int R, int ROUNDS, typename FT, bool QOK = true>
 __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef GFN_ABLATE
@@ -807,14 +810,14 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_tile_kernel(LcParams p
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = wid / tiles, tile = wid - b * tiles;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    process_tile<R, ROUNDS, true, kTileW, false, FT>(p, b, ty * 2 * ROUNDS, tx * kTileW, 2 * ROUNDS, wid, smem);
+    process_tile<R, ROUNDS, true, kTileW, false, FT, 68 * 1024, QOK>(p, b, ty * 2 * ROUNDS, tx * kTileW, 2 * ROUNDS, wid, smem);
 }
 
 // second launch: the tiles the staged kernel left in p.todo (their number is only known on the
 // device), re-cut into sub-tiles 8 cells wide and up to 4 rows high
 // worker `me` of `nworkers`: the separate second launch (round-1 path: a workgroup of its own), or the first workgroups of the
 // lean tile kernel (which finishes the plan launch's list inside its own launch, with its own -- smaller -- stage)
-template <int R, int ROUNDS, typename FT, int STAGE>
+template <int R, int ROUNDS, typename FT, int STAGE, bool QOK = true>
 __device__ __forceinline__ void second_launch_worker(const LcParams &p, unsigned char *smem, int me, int nworkers) {
     constexpr int TH = 2 * ROUNDS, SH = TH < 4 ? TH : 4;  // sub-tile height
     constexpr int SUBS = (TH / SH) * (kTileW / 8);
@@ -833,7 +836,7 @@ __device__ __forceinline__ void second_launch_worker(const LcParams &p, unsigned
         const int sub = it % SUBS;
         const int b = wid / tiles, tile = wid - b * tiles;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-        process_tile<R, 1, true, 8, true, FT, STAGE>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
+        process_tile<R, 1, true, 8, true, FT, STAGE, QOK>(p, b, ty * TH + (sub >> 1) * SH, tx * kTileW + (sub & 1) * 8, SH, wid, smem);
         __syncthreads();  // LDS (and next_item) are reused by the next sub-tile
         if (threadIdx.x == 0) next_item = part + atomicAdd(p.todo + 1, 1);
         __syncthreads();
@@ -853,10 +856,10 @@ __device__ __forceinline__ void second_launch_worker(const LcParams &p, unsigned
     }
 }
 
-template <int R, int ROUNDS, typename FT>
+template <int R, int ROUNDS, typename FT, bool QOK = true>
 __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    second_launch_worker<R, ROUNDS, FT, kStageBytes>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+    second_launch_worker<R, ROUNDS, FT, kStageBytes, QOK>(p, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 #include "local_corr_lean.h"
@@ -947,6 +950,33 @@ void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stre
 
 // the matrix-core path (local_corr_mm.h): plan (unless the refiner-input launch wrote it), the persistent tile kernel (one 16-wave
 // workgroup per CU), and the round-1 sub-tile routine for the tiles the plan listed (4 x 16-cell tiles re-cut into 4 x 8 halves)
+template <int R, int ROUNDS, typename FT, bool QOK>
+int launch_tiles_staged(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+    // per call and unconditional: the attribute is per device, a process may drive several (ADVICE r1)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS, FT, QOK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS, FT, QOK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    bool mq = false;
+    if constexpr (R >= 5 && GFN_MQ != 0) {
+        static_assert(ROUNDS == 1, "the matrix-core kernel's tiles are the round-1 kernel's 2 x 16 cells: they share the second launch");
+        mq = p.mq != 0;
+        if (mq) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mq_kernel<R, 64, FT, QOK>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMqLds);
+            hipLaunchKernelGGL((local_corr_mq_kernel<R, 64, FT, QOK>), dim3(total), dim3(kThreads), kMqLds, stream, p);
+            if (int e = gfn::check_launch("local_corr_mq_kernel")) return e;
+        }
+    }
+    if (!mq) {
+        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT, QOK>), dim3(total), dim3(kThreads), lds, stream, p);
+        if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
+    }
+    const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
+    hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS, FT, QOK>), dim3(grid2), dim3(kThreads), lds, stream, p);
+    return gfn::check_launch("local_corr_irregular_kernel");
+}
+
 template <int R, typename FT>
 int launch_mm(const LcParams &p0, hipStream_t stream) {
     LcParams p = p0;
@@ -1062,31 +1092,14 @@ int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
     // r >= 5 stages through a 32-bit buffer descriptor (local_corr_stage.h): maps of 2 GiB and more would wrap its byte count and
     // stage zeros; the general kernel (64-bit pointers) takes them
     if (R >= 5 && (long)p.C * p.H * p.W * (long)sizeof(FT) >= 0x7FFFFFF0L) return -1000;
-    // per call and unconditional: the attribute is per device, a process may drive several (ADVICE r1)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile_kernel<R, ROUNDS, FT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, ROUNDS, FT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    bool mq = false;
-    if constexpr (R >= 5 && GFN_MQ != 0) {
-        static_assert(ROUNDS == 1, "the matrix-core kernel's tiles are the round-1 kernel's 2 x 16 cells: they share the second launch");
-        mq = p.mq != 0;
-        if (mq) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mq_kernel<R, 64, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kMqLds);
-            hipLaunchKernelGGL((local_corr_mq_kernel<R, 64, FT>), dim3(total), dim3(kThreads), kMqLds, stream, p);
-            if (int e = gfn::check_launch("local_corr_mq_kernel")) return e;
-        }
+    // fp16 maps of odd width (35 x 35: scale 8 of a 280-pixel refinement pass) keep the narrow stage loads at r >= 5: an 8-byte quad
+    // of such a row is not 4-byte aligned.  A kernel instantiation of its own, so that the staging form is a compile-time constant.
+    if constexpr (R >= 5 && sizeof(FT) == 2) {
+        if (p.W & 1) return launch_tiles_staged<R, ROUNDS, FT, false>(p, total, lds, stream);
     }
-    if (!mq) {
-        hipLaunchKernelGGL((local_corr_tile_kernel<R, ROUNDS, FT>), dim3(total), dim3(kThreads), lds, stream, p);
-        if (int e = gfn::check_launch("local_corr_tile_kernel")) return e;
-    }
-    const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
-    hipLaunchKernelGGL((local_corr_irregular_kernel<R, ROUNDS, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
-    return gfn::check_launch("local_corr_irregular_kernel");
+    return launch_tiles_staged<R, ROUNDS, FT, true>(p, total, lds, stream);
 }
 
 }  // namespace

@@ -57,7 +57,7 @@ __device__ __forceinline__ int mq_cell_row(int c) { return (c >> 3) & 1; }
 __device__ __forceinline__ int mq_cell_col(int c) { return ((c >> 4) << 3) | (c & 7); }
 __device__ __forceinline__ int mq_cell_id(int r, int c) { return ((c >> 3) << 4) | (r << 3) | (c & 7); }
 
-template <int R, int C, typename FT>
+template <int R, int C, typename FT, bool QOK = true>
 __global__ __launch_bounds__(kThreads, 4) void local_corr_mq_kernel(LcParams p) {
     typedef Mq<R, C> M;
     constexpr int PW = M::PW, D = M::D, K = M::K, TS = M::TS, NC = M::NC, RP = M::RP, DS = M::DS, NBW = M::NBW, NCH = M::NCH, NW = M::NW;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_mq_kernel(LcParams p) 
         if (path == 2) {
             if (tid == 0 && (wid & 7u) == 0) atomicAdd(p.todo + 6, 8);  // informational, sampled (header word 6 -> 7: tiles the fp32 routine took here)
             __syncthreads();  // LDS is laid out anew
-            process_tile<R, 1, true, kTileW, false, FT>(p, b, row0, col0, 2, wid, smem);
+            process_tile<R, 1, true, kTileW, false, FT, 68 * 1024, QOK>(p, b, row0, col0, 2, wid, smem);
         } else if (tid == 0) {
             p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;
         }

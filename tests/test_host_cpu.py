@@ -136,8 +136,10 @@ def test_product_kernels_keep_their_register_budget():
     """spills of the product kernels are tracked, not discovered.  From the metadata of the built objects
     (tools/kernel_regs.py): the fp32 instantiations of the default local-correlation paths stay spill-free where they are today
     (lean r <= 2, the r >= 5 matrix-core kernel), the known exceptions stay bounded -- the lean r = 3 / 4 kernels carry the
-    second-launch worker path (73 spilled registers, worker workgroups only), the fp16 instantiations of the matrix-core kernel spill
-    27-39 registers at 128 VGPRs (pyramids stored in fp16, BASELINE configs[4])."""
+    second-launch worker path (73 spilled registers, worker workgroups only).  The fp16 instantiations of the r >= 5 kernels (pyramids
+    stored in fp16, BASELINE configs[4]) spilled 16-39 registers until round 4: the choice between the two staging forms was a run-time
+    flag for fp16 maps (even / odd width) and both forms' load registers were live at once; it is a template parameter now (QOK) and
+    the even-width instantiations sit at 78-105 registers, the odd-width ones at <= 128 with at most one spill."""
     import re
     import subprocess
     import sys
@@ -163,5 +165,10 @@ def test_product_kernels_keep_their_register_budget():
         elif "mq_kernel" in name:
             seen += 1
             assert vgpr <= 128, line
-            assert spill <= (40 if half else 0), line
+            assert spill <= (1 if half else 0), line
+        elif name.endswith("local_corr_tile_kernel") or "local_corr_tile_kernel" in name and "tile2" not in name:
+            r = int(re.search(r"tile_kernel(?:ILi|<)(\d)", rest).group(1))
+            if r >= 5:
+                seen += 1
+                assert vgpr <= 128 and spill == 0, line  # two workgroups of eight waves per CU
     assert seen >= 12
