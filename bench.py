@@ -136,11 +136,15 @@ def parse_args():
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
-    ap.add_argument("--pipeline", dest="pipeline", action="store_true", help="force the two-stream arrangement (see --no-pipeline)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", help="force the multi-stream arrangement (see --no-pipeline)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="one stream per scene inside the timed region (default: two -- a step's sampling + solve run on a second stream under "
-                         "the next step's match, the way gfnet_amd.evaluate streams batches; the roofline op is timed in separate, "
-                         "un-overlapped steps either way, and the default line reports the one-stream rate as `unpipelined_steps`)")
+                    help="one stream per scene inside the timed region (default for one-scene workloads: the stages of a step on streams of "
+                         "their own -- see --stages --, a step's later stages beside the next steps' earlier ones, the way a stream of "
+                         "batches goes through the path; the roofline op is timed in separate, un-overlapped steps either way, and the "
+                         "default line reports the one-stream rate as `unpipelined_steps`)")
+    ap.add_argument("--stages", type=int, choices=(2, 3), default=3,
+                    help="stages of the pipelined steps of a one-scene workload: 3 = first pass | refinement pass + post-processing | "
+                         "sampling + solve on three streams (default), 2 = match | sampling + solve")
     ap.set_defaults(pipeline=None)  # None: two streams for one-scene workloads, one stream per scene for the three-scene pyramid workload
                                     # (six streams slow it down: 6.8 k -> 5.5 k pairs/s, round 3)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -245,9 +249,14 @@ class SceneRunner:
       way a stream of batches goes through the path in deployment (448b32: 3.53 -> 3.19 ms per step).  OFF for the timed region
       of the driver's line: the overlapped kernels take CUs from the roofline op while it is being timed (96.5 -> 107 us), and
       six streams slow the three-scene workload down; the default single-GPU 448b32 run reports it as `pipelined_steps` instead
-      (a secondary leg after the timed region, like `with_conv_stacks`); --pipeline puts it into the timed region."""
+      (a secondary leg after the timed region, like `with_conv_stacks`); --pipeline puts it into the timed region.
+    * Round 4, one-scene workloads: THREE stages on three streams -- first pass | refinement pass + post-processing | sampling + solve
+      (GFNet.match_first_pass / match_second_pass): step k + 1's first pass runs beside step k's refinement pass, and every kernel
+      still sees the whole batch.  The heavy kernels fill a CU's register file, so the overlap is workgroup by workgroup -- a
+      memory-bound refiner_input launch of one stage fills in beside an instruction-bound local correlation of the other:
+      10.56 k -> 11.32 k pairs/s (448b32).  stages=2 keeps the round-4 two-stage form (--stages 2)."""
 
-    def __init__(self, scenes, pipeline=False):
+    def __init__(self, scenes, pipeline=False, stages=3):
         import torch
 
         from gfnet_amd import parallel
@@ -258,9 +267,12 @@ class SceneRunner:
         self.streams = []
         # streams TESTED to run side by side (the runtime deals streams onto 4 hardware queues, not one to one: parallel.py); the
         # same ones for every runner of the process
-        pool = parallel.concurrent_streams(2 * len(scenes) if pipeline else (len(scenes) if len(scenes) > 1 else 0))
+        self.stages3 = pipeline and len(scenes) == 1 and stages == 3
+        pool = parallel.concurrent_streams(3 if self.stages3 else 2 * len(scenes) if pipeline else (len(scenes) if len(scenes) > 1 else 0))
         for k in range(len(scenes)):
             pair = (pool[2 * k], pool[2 * k + 1]) if pipeline else ((pool[k],) * 2 if len(scenes) > 1 else None)
+            if self.stages3:
+                pair = (pool[0], pool[2], pool[1])  # first pass, sampling + solve, refinement pass
             if pair is not None:
                 for st in set(pair):
                     st.wait_stream(main)  # the scenes' inputs were produced on the current stream
@@ -275,10 +287,24 @@ class SceneRunner:
             if pair is None:
                 outs.append(sc.step(seed))
                 continue
-            ms, fs = pair
-            with torch.cuda.stream(ms):
-                warp, cert = sc.match()
-                done = ms.record_event()
+            if self.stages3:
+                m1, fs, ms = pair
+                with torch.cuda.stream(m1):
+                    corresps = sc.match_first()
+                    done1 = m1.record_event()
+                with torch.cuda.stream(ms):
+                    ms.wait_event(done1)
+                    for per_itr in corresps.values():
+                        for c in per_itr.values():
+                            c["flow"].record_stream(ms)
+                            c["certainty"].record_stream(ms)
+                    warp, cert = sc.match_second(corresps)
+                    done = ms.record_event()
+            else:
+                ms, fs = pair
+                with torch.cuda.stream(ms):
+                    warp, cert = sc.match()
+                    done = ms.record_event()
             with torch.cuda.stream(fs):
                 fs.wait_event(done)
                 warp.record_stream(fs)
@@ -286,7 +312,7 @@ class SceneRunner:
                 outs.append(sc.finish(warp, cert, seed))
         for o, pair in zip(outs, self.streams):
             if pair is not None:
-                main.wait_stream(pair[1])
+                main.wait_stream(pair[1])  # (the sampling + solve stream in every arrangement)
                 for t in o:
                     t.record_stream(main)
         return outs
@@ -306,8 +332,8 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     with torch.inference_mode(False):
         scenes = [Scene(S, wl["pairs"], wl["num_itr"], dtype, conv_stack, dev, rank) for S in wl["sizes"]]
     main_scene = scenes[min(1, len(scenes) - 1)]
-    # eager steps: a one-scene workload in two stages on two streams (as its own run does by default), the three-scene workload on
-    # one stream per scene
+    # eager steps: a one-scene workload in three stages on three streams (as its own run does by default), the three-scene workload
+    # on one stream per scene
     runner = SceneRunner(scenes, pipeline=len(scenes) == 1)
     graphs, graph_note = False, None
     with torch.inference_mode():
@@ -384,7 +410,7 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     us = float(np.mean([a.elapsed_time(b) for a, b in events])) * 1e3
     fbytes = 2 if dtype == torch.float16 and ops.NATIVE_FP16 else 4
     nbytes = algorithmic_bytes_local_corr(2 * wl["pairs"], 32, side_of("4", S0), main_scene.grids[2], 4, fbytes)
-    eager_mode = "eager launches" + (", two stages on two streams" if len(scenes) == 1 else ", one stream per scene")
+    eager_mode = "eager launches" + (", three stages on three streams (first pass | refinement pass | sampling + solve)" if len(scenes) == 1 else ", one stream per scene")
     graph_mode = ("hipGraph replay (seeds of the capture): " + ("one captured step per scene and stream; the largest scene as " if len(scenes) > 1 else "") +
                   "two graphs on two streams (match | sampling + solve), a step's second stage under the next step's first")
     dt_graph = dt if graphs else None
@@ -450,7 +476,7 @@ def main():
     main_scene = scenes[min(1, len(scenes) - 1)] if len(scenes) > 1 else scenes[0]  # the 448 scene of the pyramid workload
     pairs_per_step = B * len(scenes)
 
-    runner = SceneRunner(scenes, pipeline=args.pipeline)
+    runner = SceneRunner(scenes, pipeline=args.pipeline, stages=args.stages)
 
     def step(seed):
         outs = runner.step(seed)
@@ -616,7 +642,10 @@ def main():
         "config": {"workload": wl["label"], "workload_key": args.workload, "pairs_per_gpu": pairs_per_step,
                    "image_sizes": wl["sizes"], "num_itr": wl["num_itr"], "feature_storage": wl["dtype"],
                    "symmetric": True, "upsample_pass": "1.25x (560 at 448)", "attenuate_cert": True,
-                   "step_pipeline": "a step's sampling + solve (second stream) run under the next step's match" if args.pipeline else "off",
+                   "step_pipeline": ("off" if not args.pipeline else
+                                     "three stages on three streams, every kernel on the whole batch: first pass | refinement pass + post-processing | "
+                                     "sampling + solve; a step's later stages run beside the next steps' earlier ones" if runner.stages3 else
+                                     "a step's sampling + solve (second stream) run under the next step's match"),
                    "flow_noise": f"stand-in increment = true warp + N(0,({FLOW_NOISE_PX}/S)^2) - flow, fresh realisation per iteration",
                    "stages": "corr_softargmax, (refiner_input + local_corr + flow_update) x scales x num_itr for both passes, resize, "
                              "match_post, sample(2 draws without replacement + KDE 20000^2), RANSAC(<= 2000 hypotheses, OpenCV's confidence-0.99999 "

@@ -168,6 +168,14 @@ class Scene:
         """Both passes of the coarse-to-fine loop + match post-processing: (warp, certainty) of the batch."""
         return self.model.match_pyramids(self.pyr[0], self.pyr[1], self.pyr_up[0], self.pyr_up[1], batched=True)
 
+    def match_first(self):
+        """First pass only (its corresps): GFNet.match_first_pass."""
+        return self.model.match_first_pass(self.pyr[0], self.pyr[1])
+
+    def match_second(self, corresps):
+        """Refinement pass + post-processing on a first pass's corresps: (warp, certainty)."""
+        return self.model.match_second_pass(corresps, self.pyr_up[0], self.pyr_up[1], batched=True)
+
     def finish(self, warp, cert, seed):
         """Balanced sampling + homography solve on a batch's (warp, certainty)."""
         from gfnet_amd.estimation import estimate_homographies

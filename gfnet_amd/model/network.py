@@ -348,8 +348,20 @@ class GFNet(nn.Module):
     def match_pyramids(self, pyr0, pyr1, pyr0_up=None, pyr1_up=None, batched=True):
         """match() on precomputed feature pyramids: the 448 pass, the optional 560 refinement pass
         seeded by it (upsample_preds), certainty attenuation, post-processing."""
+        return self.match_second_pass(self.match_first_pass(pyr0, pyr1), pyr0_up, pyr1_up, batched=batched)
+
+    # The two halves of match_pyramids as calls of their own: a host that streams batches can run the first pass of batch k + 1
+    # beside the refinement pass of batch k (each on a HIP stream of its own; every kernel still sees the whole batch).
+    @torch.inference_mode()
+    def match_first_pass(self, pyr0, pyr1):
+        """The first (initial-resolution) coarse-to-fine pass: network.py:285-331.  Returns its corresps."""
         self.train(False)
-        corresps = self.forward_pyramids(pyr0, pyr1, (self.h_resized, self.w_resized), symmetric=self.symmetric)
+        return self.forward_pyramids(pyr0, pyr1, (self.h_resized, self.w_resized), symmetric=self.symmetric)
+
+    @torch.inference_mode()
+    def match_second_pass(self, corresps, pyr0_up=None, pyr1_up=None, batched=True):
+        """The optional refinement pass seeded by the first pass's corresps (upsample_preds), certainty attenuation,
+        post-processing: network.py:332-384."""
         corresps_up = None
         if self.upsample_preds:
             hs, ws = self.upsample_res

@@ -320,3 +320,30 @@ def test_the_two_stage_hipgraph_replay_equals_the_eager_steps():
                 finite = bool(torch.isfinite(Hg).all())
             assert same and finite, f"replay {rep}"
         torch.cuda.synchronize()
+
+
+def test_three_stage_streaming_of_batches_equals_the_one_stream_steps():
+    """Round 4: bench.py's default for one-scene workloads runs a step as three stages on three HIP streams (first pass | refinement
+    pass + post-processing | sampling + solve: GFNet.match_first_pass / match_second_pass), a step's later stages beside the next
+    steps' earlier ones.  Every step's H and sampled matches are bit-identical to the same steps on one stream (same seeds, same
+    generator state), step after step -- the stages only meet through events."""
+    import bench
+    from gfnet_amd._synthetic import Scene
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with torch.inference_mode(False):
+        sc = Scene(224, 3, [1] * 5, torch.float32, "off", dev, 0)
+    with torch.inference_mode():
+        torch.manual_seed(3)
+        ref = []
+        for i in range(4):
+            H, good = sc.step(i)
+            ref.append((H.clone(), good.clone()))
+        torch.cuda.synchronize()
+        runner = bench.SceneRunner([sc], pipeline=True, stages=3)
+        assert runner.stages3 and len({s.cuda_stream for s in runner.streams[0]}) == 3
+        torch.manual_seed(3)
+        outs = [runner.step(i)[0] for i in range(4)]  # four steps in flight back to back
+        torch.cuda.synchronize()
+        for i, ((H, good), (Hr, gr)) in enumerate(zip(outs, ref)):
+            assert torch.equal(H, Hr) and torch.equal(good, gr), f"step {i}"
