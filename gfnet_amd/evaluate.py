@@ -75,12 +75,27 @@ def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOL
     mine = pairs[lo:hi]
     errors = np.full(len(mine), np.nan, np.float64)
     elapsed = 0.0
-    # Batches stream through two HIP streams: the matching of batch k + 1 (chip-wide launches) runs while batch k is sampled and
-    # solved on the second stream (a third of that stage is one-workgroup-per-pair kernels -- curve sort, radix select, LM finish --
+    # Batches stream through two (or three, below) HIP streams: the matching of batch k + 1 (chip-wide launches) runs while batch k
+    # is sampled and solved on the second stream (a third of that stage is one-workgroup-per-pair kernels -- curve sort, radix select, LM finish --
     # that leave most of the chip idle), and batch k's 3x3 matrices come back through pinned memory behind an event instead of a
     # blocking copy.  bench.py times the same arrangement (`config.step_pipeline`).
-    ms, fs = parallel.concurrent_streams(2)  # two streams on different hardware queues (parallel.py)
+    # A matcher that offers the matching in two calls (GFNet.match_batch_first / match_batch_second: first pass | refinement pass)
+    # gets a third stream: batch k + 1's first pass beside batch k's refinement pass (bench.py: 10.6 k -> 11.3 k pairs/s).
+    three = hasattr(matcher, "match_batch_first") and hasattr(matcher, "match_batch_second")
+    pool = parallel.concurrent_streams(3 if three else 2)  # streams tested to sit on different hardware queues (parallel.py)
+    m1, ms, fs = (pool[0], pool[1], pool[2]) if three else (None, pool[0], pool[1])
     pending = None  # (first index, n, ground-truth Hs, sizes, pinned H, event)
+
+    def hand_over(obj, stream):  # tensors produced on one stream, consumed on another: tell the caching allocator
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                obj.record_stream(stream)
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                hand_over(v, stream)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                hand_over(v, stream)
 
     def settle(p):
         first, n_, Hs_, (w1_, h1_), Hpin, ev = p
@@ -110,19 +125,31 @@ def evaluate(matcher, root, batch_size=32, num_samples=5000, thresholds=THRESHOL
         sa, sb = torch.stack(ims_a), torch.stack(ims_b)
         t_load += time.perf_counter() - t0  # decoding on the host: not part of the reference's per-pair runtime either (estimation.py:56)
         with torch.inference_mode():
-            with torch.cuda.stream(ms):
-                A, Bt = sa.cuda(non_blocking=True), sb.cuda(non_blocking=True)
-                if hasattr(matcher, "match_batch"):
-                    warp, cert = matcher.match_batch(A, Bt)
+            if three:
+                with torch.cuda.stream(m1):
+                    A, Bt = sa.cuda(non_blocking=True), sb.cuda(non_blocking=True)
+                    state = matcher.match_batch_first(A, Bt)
+                    first_done = m1.record_event()
+                with torch.cuda.stream(ms):
+                    ms.wait_event(first_done)
+                    hand_over(state, ms)
+                    warp, cert = matcher.match_batch_second(state)
                     good = None
-                else:  # the reference's per-pair surface
-                    gs = []
-                    for k in range(n):
-                        w_, c_ = matcher.match(A[k:k + 1], Bt[k:k + 1])
-                        gs.append(matcher.sample(w_, c_, num_samples)[0])
-                    good = torch.stack(gs)
-                    warp = cert = None
-                matched = ms.record_event()
+                    matched = ms.record_event()
+            else:
+                with torch.cuda.stream(ms):
+                    A, Bt = sa.cuda(non_blocking=True), sb.cuda(non_blocking=True)
+                    if hasattr(matcher, "match_batch"):
+                        warp, cert = matcher.match_batch(A, Bt)
+                        good = None
+                    else:  # the reference's per-pair surface
+                        gs = []
+                        for k in range(n):
+                            w_, c_ = matcher.match(A[k:k + 1], Bt[k:k + 1])
+                            gs.append(matcher.sample(w_, c_, num_samples)[0])
+                        good = torch.stack(gs)
+                        warp = cert = None
+                    matched = ms.record_event()
             with torch.cuda.stream(fs):
                 fs.wait_event(matched)
                 for t in (warp, cert, good):

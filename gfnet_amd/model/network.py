@@ -413,6 +413,28 @@ class GFNet(nn.Module):
             u0, u1 = pyramids(self.upsample_res, True)
         return self.match_pyramids(p0, p1, u0, u1, batched=True)
 
+    # match_batch in two calls, for a host that streams batches through three HIP streams (gfnet_amd.evaluate): the first pass of
+    # batch k + 1 runs beside the refinement pass of batch k.  match_batch_second(match_batch_first(a, b)) == match_batch(a, b).
+    @torch.inference_mode()
+    def match_batch_first(self, im_a, im_b, mode="bicubic"):
+        from ..utils.image import resize_normalise
+
+        im_a, im_b = im_a.cuda(), im_b.cuda()
+        res = (self.h_resized, self.w_resized)
+        p0, p1 = self.extract_features(torch.cat([resize_normalise(im_a, res, mode), resize_normalise(im_b, res, mode)]), False)
+        return {"corresps": self.match_first_pass(p0, p1), "im_a": im_a, "im_b": im_b}
+
+    @torch.inference_mode()
+    def match_batch_second(self, state):
+        from ..utils.image import resize_normalise
+
+        u0 = u1 = None
+        if self.upsample_preds:
+            ims = torch.cat([resize_normalise(state["im_a"], self.upsample_res, "bilinear"),
+                             resize_normalise(state["im_b"], self.upsample_res, "bilinear")])
+            u0, u1 = self.extract_features(ims, True)
+        return self.match_second_pass(state["corresps"], u0, u1, batched=True)
+
     # ---- sample (network.py:385-414) --------------------------------------------------------------------
     def sample(self, matches, certainty, num=5_000):
         matches = matches.reshape(-1, 4)

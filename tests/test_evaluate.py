@@ -143,6 +143,37 @@ def test_evaluate_recovers_known_homographies(tmp_path):
     assert res["time"] > 0
 
 
+class _TwoCallMatcher(_OracleMatcher):
+    """The same matcher with the matching offered in two calls (GFNet.match_batch_first / match_batch_second): evaluate() then
+    streams batches through three HIP streams."""
+
+    def match_batch_first(self, A, B):
+        self.first_streams = getattr(self, "first_streams", []) + [torch.cuda.current_stream().cuda_stream]
+        return {"A": A, "B": B, "nested": [A.new_zeros(3), (B.new_ones(2),)]}
+
+    def match_batch_second(self, state):
+        self.second_streams = getattr(self, "second_streams", []) + [torch.cuda.current_stream().cuda_stream]
+        return self.match_batch(state["A"], state["B"])
+
+
+@pytest.mark.gpu
+def test_evaluate_streams_a_two_call_matcher_through_three_streams(tmp_path):
+    from gfnet_amd import evaluate
+
+    sizes = [(96, 96)] * 6
+    Hs = _homographies(6, 64, corner=0.08)
+    _write_dataset(str(tmp_path), Hs, sizes)
+    torch.manual_seed(5)  # the sampler's seeds come from torch's generator
+    ref = evaluate.evaluate(_OracleMatcher(Hs), str(tmp_path), batch_size=2, num_samples=2000)
+    m = _TwoCallMatcher(Hs)
+    torch.manual_seed(5)
+    res = evaluate.evaluate(m, str(tmp_path), batch_size=2, num_samples=2000)
+    assert m.calls == [2, 2, 2]
+    assert len(set(m.first_streams)) == 1 and len(set(m.second_streams)) == 1 and m.first_streams[0] != m.second_streams[0]
+    np.testing.assert_array_equal(res["errors"], ref["errors"])  # same matches, same seeds: the same homographies
+    assert np.all(res["errors"] < 1e-2)
+
+
 @pytest.mark.gpu
 def test_match_batch_resizes_and_calls_the_backbone():
     """GFNet.match_batch: resize + normalise per pass (448 bicubic, 560 bilinear), backbone on cat(A, B)."""
@@ -170,3 +201,37 @@ def test_match_batch_resizes_and_calls_the_backbone():
     assert shape == (4, 3, 448, 448) and up is False
     want = oracle.resize_normalise(torch.cat((a, b)).numpy(), (448, 448), "bicubic")
     np.testing.assert_allclose(x.cpu().numpy(), want, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_match_batch_in_two_calls_equals_match_batch():
+    """GFNet.match_batch_first + match_batch_second (what evaluate() streams through three HIP streams) return exactly
+    match_batch's warp and certainty -- toy backbone (pooled image channels), the refiners' real conv stacks, both passes."""
+    import math
+
+    import torch.nn.functional as F
+    from gfnet_amd.model.network import GFNet
+
+    chs = {"16": 64, "8": 64, "4": 32, "2": 16, "1": 8}
+
+    def backbone(x, upsample):
+        pyr = {}
+        for s in (["8", "4", "2", "1"] if upsample else ["16", "8", "4", "2", "1"]):
+            k = int(s)
+            f = F.avg_pool2d(x, k) if k > 1 else x
+            if s == "16":  # the coarsest features come from the patch-14 trunk: 32 x 32 at 448 (network.py:329's grid rule)
+                f = F.adaptive_avg_pool2d(x, (x.shape[-2] // 14, x.shape[-1] // 14))
+            f = f.repeat(1, math.ceil(chs[s] / 3), 1, 1)[:, :chs[s]]
+            f = f * torch.linspace(0.5, 1.5, chs[s], device=x.device).view(1, -1, 1, 1)
+            pyr[s] = f.contiguous()
+        n = x.shape[0] // 2
+        return {s: f[:n] for s, f in pyr.items()}, {s: f[n:] for s, f in pyr.items()}
+
+    conf = {"matcher": {"num_grid": [32, 32, 64, 128, 256], "radius": [7, 6, 4, 2, 0], "num_itr": [1, 1, 1, 1, 1],
+                        "displacement_dim": [64, 64, 32, 16, 8]}, "encoder_cfg": {"feat_chs": [64, 32, 16, 8]}}
+    torch.manual_seed(0)
+    model = GFNet(conf, symmetric=True, upsample_preds=True, attenuate_cert=True, backbone=backbone).cuda().eval()
+    a, b = torch.rand(1, 3, 60, 80), torch.rand(1, 3, 60, 80)
+    warp, cert = model.match_batch(a, b)
+    warp2, cert2 = model.match_batch_second(model.match_batch_first(a, b))
+    assert torch.isfinite(warp).all() and torch.equal(warp, warp2) and torch.equal(cert, cert2)
