@@ -373,9 +373,11 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
             try:
                 longest = max(scenes, key=lambda sc: sc.size)
                 # (streams from the tested pool: one per scene and one more for the second stage -- parallel.concurrent_streams)
-                pool = parallel.concurrent_streams(len(scenes) + 1)
+                pool = parallel.concurrent_streams(max(len(scenes) + 1, 3))
                 for k, sc in enumerate(scenes):
-                    if sc is longest:
+                    if len(scenes) == 1:
+                        sc.capture_pipelined(0, streams=pool[:3], stages=3)  # the three stages of the eager steps, as graphs
+                    elif sc is longest:
                         sc.capture_pipelined(0, streams=(pool[k], pool[len(scenes)]))
                     else:
                         sc.capture(0, stream=pool[k])
@@ -411,8 +413,10 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     fbytes = 2 if dtype == torch.float16 and ops.NATIVE_FP16 else 4
     nbytes = algorithmic_bytes_local_corr(2 * wl["pairs"], 32, side_of("4", S0), main_scene.grids[2], 4, fbytes)
     eager_mode = "eager launches" + (", three stages on three streams (first pass | refinement pass | sampling + solve)" if len(scenes) == 1 else ", one stream per scene")
-    graph_mode = ("hipGraph replay (seeds of the capture): " + ("one captured step per scene and stream; the largest scene as " if len(scenes) > 1 else "") +
-                  "two graphs on two streams (match | sampling + solve), a step's second stage under the next step's first")
+    graph_mode = ("hipGraph replay (seeds of the capture): " +
+                  ("one captured step per scene and stream; the largest scene as two graphs on two streams (match | sampling + solve), a step's "
+                   "second stage under the next step's first" if len(scenes) > 1 else
+                   "three graphs on three streams (first pass | refinement pass + post-processing | sampling + solve), two copies each"))
     dt_graph = dt if graphs else None
     if not graphs or dt_eager < dt:  # `value` = the faster of the two ways to drive the same kernels; both are reported
         dt = dt_eager
@@ -563,13 +567,14 @@ def main():
         if args.conv_stack == "off" and world == 1 and not args.no_stack_leg:
             with torch.inference_mode(False):  # module parameters must be ordinary tensors (the packed-parameter cache reads their versions)
                 scenes2 = [Scene(S, B, wl["num_itr"], dtype, "amp", dev, rank) for S in wl["sizes"]]
-            runner2 = SceneRunner(scenes2)
+            runner2 = SceneRunner(scenes2, pipeline=args.pipeline, stages=args.stages)  # the same arrangement as the timed region
             for i in range(2):
                 runner2.step(i)
             torch.cuda.synchronize()
             n2 = max(3, min(args.steps, 10))
             dt2, _ = timed_loop(lambda i: runner2.step(0), n2, torch.cuda.synchronize)
             stack_leg = {"value": round(pairs_per_step * n2 / dt2, 2), "unit": "pairs/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
+                         "step_pipeline": "as the timed region" if args.pipeline else "off",
                          "refiner_conv_stack": "reference architecture, random-init, HIP conv_stack kernels, conv_precision='amp' (fp16 maps, "
                                                "fp16 operands, fp32 accumulation: model/network.py:560-562)"}
             del scenes2

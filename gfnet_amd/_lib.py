@@ -103,6 +103,7 @@ def check(code, what):
         msg = lib().gfn_last_error().decode()
         # gfn_local_corr_fwd wants its scratch counters zero on entry and only a call that ran to the end leaves them so
         # (include/gfnet_hip.h): after any failure the cached buffers are dropped, the next call gets freshly zeroed ones
+        _retired.extend(_scratch.values())  # (not freed: a captured graph may still name them)
         _scratch.clear()
         raise GfnError(f"{what} failed ({code}): {msg}")
 
@@ -130,6 +131,7 @@ def require_gpu(*tensors):
 
 
 _scratch = {}
+_retired = []  # outgrown or dropped scratch buffers, kept alive for captured graphs that still name them
 
 
 def scratch(device, nbytes):
@@ -139,6 +141,11 @@ def scratch(device, nbytes):
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
+        # a buffer that is outgrown is RETIRED, not freed: a hipGraph captured on this stream keeps launching kernels with its
+        # address (round 4: two scenes of different sizes captured on one stream -- the second capture grew the buffer and the first
+        # graph's replays ended in a memory fault).  A few MB per growth step, a handful of steps per process.
+        if buf is not None:
+            _retired.append(buf)
         # zero-filled: gfn_local_corr_fwd wants its counters zero on entry and leaves them zero (include/gfnet_hip.h)
         buf = torch.zeros((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
         _scratch[key] = buf

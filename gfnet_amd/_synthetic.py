@@ -225,57 +225,61 @@ class Scene:
             self._graph.replay()
         return self._graph_out
 
-    # The two-stream arrangement of bench.py's SceneRunner as graphs: match and finish captured APART on a stream each, twice each
-    # (a match graph's outputs are static buffers: the second copy lets step i + 1's match run while step i's finish still reads
-    # the first), events between the replays.  A step's sampling + solve -- a third of its time one-workgroup-per-pair kernels --
-    # then runs under the next step's matching, as in the eager pipeline, at four launches per step.
-    def capture_pipelined(self, seed=0, warmup=2, streams=None):
+    # The multi-stream arrangements of bench.py's SceneRunner as graphs: the stages of a step captured APART on a stream each --
+    # stages=2: match | sampling + solve; stages=3: first pass | refinement pass + post-processing | sampling + solve --, twice each
+    # (a stage graph's outputs are static buffers: the second copy lets step i + 1's stage run while step i's next stage still reads
+    # the first), events between the replays.  A step's later stages then run beside the next steps' earlier ones, as in the eager
+    # pipeline, at one launch per stage and step.
+    def capture_pipelined(self, seed=0, warmup=2, streams=None, stages=2):
         from gfnet_amd import ops
 
         if ops.kernel_events is not None or ops.kernel_counters is not None:
             raise RuntimeError("Scene.capture_pipelined: switch ops.kernel_events / ops.kernel_counters off first")
+        if stages == 2:
+            fns = [lambda _: self.match(), lambda m: self.finish(m[0], m[1], seed)]
+        else:
+            fns = [lambda _: self.match_first(), lambda c: self.match_second(c), lambda m: self.finish(m[0], m[1], seed)]
+        n = len(fns)
         cur = torch.cuda.current_stream()
-        self._ms, self._fs = streams if streams is not None else (torch.cuda.Stream(), torch.cuda.Stream())
-        self._ms.wait_stream(cur)
-        self._fs.wait_stream(cur)
-        with torch.cuda.stream(self._ms):
-            for _ in range(warmup):
-                warp, cert = self.match()
-        self._ms.synchronize()
-        with torch.cuda.stream(self._fs):
-            for _ in range(warmup):
-                self.finish(warp, cert, seed)
-        self._fs.synchronize()
-        self._mgraph, self._fgraph, self._mout, self._fout = [], [], [], []
-        for _ in range(2):
-            mg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(mg, stream=self._ms):
-                mout = self.match()
-            torch.cuda.synchronize()
-            fg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fg, stream=self._fs):
-                fout = self.finish(mout[0], mout[1], seed)
-            torch.cuda.synchronize()
-            self._mgraph.append(mg)
-            self._fgraph.append(fg)
-            self._mout.append(mout)
-            self._fout.append(fout)
-        self._turn, self._fdone = 0, [None, None]
-        return self._fout
+        self._pst = list(streams) if streams is not None else [torch.cuda.Stream() for _ in range(n)]
+        if len(self._pst) != n:
+            raise ValueError(f"Scene.capture_pipelined: {n} stages need {n} streams")
+        self._ms, self._fs = self._pst[0], self._pst[-1]
+        x = None
+        for st, fn in zip(self._pst, fns):  # lazy module state, every stream's scratch buffers, the allocator's pools
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                for _ in range(max(warmup, 1)):
+                    y = fn(x)
+            st.synchronize()
+            x = y
+        self._pgraph, self._pout = [[None, None] for _ in range(n)], [[None, None] for _ in range(n)]
+        for k in range(2):
+            x = None
+            for j, (st, fn) in enumerate(zip(self._pst, fns)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    x = fn(x)
+                torch.cuda.synchronize()
+                self._pgraph[j][k], self._pout[j][k] = g, x
+        self._turn, self._pdone = 0, [[None, None] for _ in range(n)]
+        return self._pout[-1]
 
     def replay_pipelined(self):
-        """One step through the two captured stages; returns this step's static outputs (H, good matches) and the event that says
+        """One step through the captured stages; returns this step's static outputs (H, good matches) and the event that says
         they are complete (they are overwritten by the replay after next)."""
         k = self._turn
         self._turn ^= 1
-        if self._fdone[k] is not None:
-            self._ms.wait_event(self._fdone[k])  # the finish of two steps ago has read this match graph's outputs
-        with torch.cuda.stream(self._ms):
-            self._mgraph[k].replay()
-        mdone = self._ms.record_event()
-        self._fs.wait_event(mdone)
-        with torch.cuda.stream(self._fs):
-            self._fgraph[k].replay()
-        self._fdone[k] = self._fs.record_event()
-        return self._fout[k], self._fdone[k]
+        n = len(self._pst)
+        prev = None
+        for j, st in enumerate(self._pst):
+            if j + 1 < n and self._pdone[j + 1][k] is not None:
+                st.wait_event(self._pdone[j + 1][k])  # the next stage of two steps ago has read this copy's outputs
+            if prev is not None:
+                st.wait_event(prev)
+            with torch.cuda.stream(st):
+                self._pgraph[j][k].replay()
+            prev = st.record_event()
+            self._pdone[j][k] = prev
+        return self._pout[-1][k], prev
 

@@ -347,3 +347,50 @@ def test_three_stage_streaming_of_batches_equals_the_one_stream_steps():
         torch.cuda.synchronize()
         for i, ((H, good), (Hr, gr)) in enumerate(zip(outs, ref)):
             assert torch.equal(H, Hr) and torch.equal(good, gr), f"step {i}"
+
+
+def test_three_stage_hipgraph_replay_and_graphs_of_two_scenes_on_one_stream():
+    """Round 4: (a) Scene.capture_pipelined(stages=3) -- first pass | refinement pass + post-processing | sampling + solve as graphs
+    on three streams, two copies each -- replays the eager steps bit for bit; (b) two scenes of different sizes captured one after
+    the other on ONE stream: the second capture outgrows the stream's scratch buffer, which used to free the buffer the first graph's
+    kernels still name (memory fault on replay); outgrown buffers are retired now (gfnet_amd/_lib.py) and both graphs replay."""
+    from gfnet_amd import parallel
+    from gfnet_amd._synthetic import Scene
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with torch.inference_mode(False):
+        sc = Scene(224, 2, [1] * 5, torch.float16, "off", dev, 0)
+        small = Scene(224, 1, [1] * 5, torch.float32, "off", dev, 0)
+        big = Scene(448, 2, [1] * 5, torch.float32, "off", dev, 0)
+    with torch.inference_mode():
+        torch.manual_seed(11)
+        eager = []
+        for _ in range(4):
+            He, ge = sc.step(5)
+            eager.append((He.clone(), ge.clone()))
+        torch.cuda.synchronize()
+        torch.manual_seed(11)
+        sc.capture_pipelined(5, warmup=2, streams=parallel.concurrent_streams(3), stages=3)
+        for rep in range(6):
+            (Hg, gg), done = sc.replay_pipelined()
+            He, ge = eager[2 + (rep & 1)]
+            with torch.cuda.stream(sc._fs):
+                same = bool(torch.equal(Hg, He)) and bool(torch.equal(gg, ge))
+            assert same, f"replay {rep}"
+        torch.cuda.synchronize()
+        # (b)
+        st = torch.cuda.Stream()
+        torch.manual_seed(2)
+        Hs, _ = small.capture(1, stream=st)
+        small.replay()  # (a capture runs nothing: the static outputs are filled by the first replay)
+        with torch.cuda.stream(st):
+            first = Hs.clone()
+        torch.manual_seed(2)
+        Hb, _ = big.capture(1, stream=st)   # needs a larger scratch buffer on the same stream
+        for _ in range(3):
+            small.replay()
+            big.replay()
+            with torch.cuda.stream(st):
+                ok = bool(torch.equal(Hs, first)) and bool(torch.isfinite(Hb).all())
+            assert ok
+        torch.cuda.synchronize()

@@ -1,0 +1,58 @@
+"""hipGraph layouts of the three-scene pyramid workload on the four hardware queues (round 4):
+   python tools/probe_graph_layouts.py [steps]
+   A: one graph per scene, the largest scene in two stages (4 streams)        -- bench.py's layout
+   B: the largest scene in three stages, the two small scenes one after the other on the fourth stream
+   C: the largest scene in three stages, the middle scene on the fourth stream, the small scene behind the largest's first stage"""
+import os
+import sys
+import time
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from gfnet_amd import parallel  # noqa: E402
+from gfnet_amd._synthetic import WORKLOADS, Scene  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+wl = WORKLOADS["pyr-fp16"]
+dev = torch.device("cuda", 0)
+pool = parallel.concurrent_streams(4)
+
+
+def scenes():
+    return [Scene(S, wl["pairs"], wl["num_itr"], torch.float16, "off", dev, 0) for S in wl["sizes"]]
+
+
+def timed(name, step):
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{name}: {3 * wl['pairs'] * steps / dt:.0f} pairs/s, {dt / steps * 1e3:.3f} ms per step", flush=True)
+
+
+with torch.inference_mode():
+    s224, s448, s672 = scenes()
+    s224.capture(0, stream=pool[0])
+    s448.capture(0, stream=pool[1])
+    s672.capture_pipelined(0, streams=(pool[2], pool[3]))
+    timed("A  224 | 448 | 672 in two stages", lambda: (s224.replay(), s448.replay(), s672.replay_pipelined()))
+    del s224, s448, s672
+    s224, s448, s672 = scenes()
+    s224.capture(0, stream=pool[3])
+    s448.capture(0, stream=pool[3])
+    s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
+    timed("B  672 in three stages | 224 then 448 on one stream", lambda: (s672.replay_pipelined(), s224.replay(), s448.replay()))
+    del s224, s448, s672
+    s224, s448, s672 = scenes()
+    s224.capture(0, stream=pool[0])
+    s448.capture(0, stream=pool[3])
+    s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
+    timed("C  672 in three stages (224 behind its first stage) | 448", lambda: (s672.replay_pipelined(), s224.replay(), s448.replay()))
+    del s224, s448
+    timed("   672 alone in three stages", lambda: s672.replay_pipelined())
