@@ -66,13 +66,19 @@ _stream_pool = {}
 def _overlap(a, b, cycles=400_000):
     """True when work on streams a and b runs concurrently (a one-workgroup spin on each: ~0.2 ms alone)."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    torch.cuda.synchronize()
-    with torch.cuda.stream(a):
-        ev[0].record()
-        torch.cuda._sleep(cycles)
-        ev[1].record()
-    torch.cuda.synchronize()
-    alone = ev[0].elapsed_time(ev[1])
+
+    def spin_alone(st):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            ev[0].record()
+            torch.cuda._sleep(cycles)
+            ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+    spin_alone(a)  # clocks up, both streams' queues created: the reference time below is taken warm
+    spin_alone(b)
+    alone = min(spin_alone(a), spin_alone(b))
     start = torch.cuda.Event()
     start.record()          # both streams wait for the same point, then spin
     a.wait_event(start)
