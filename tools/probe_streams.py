@@ -1,3 +1,6 @@
+"""Which streams of a process share a hardware queue (GPU box): python tools/probe_streams.py
+   Nine fresh torch streams, pairwise overlap test of gfnet_amd.parallel (two one-workgroup spin kernels: 1 = they run side by side,
+   0 = one after the other: the same hardware queue), then the pool parallel.concurrent_streams builds from such tests."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
