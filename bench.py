@@ -145,7 +145,7 @@ def parse_args():
     ap.add_argument("--stages", type=int, choices=(2, 3), default=3,
                     help="stages of the pipelined steps of a one-scene workload: 3 = first pass | refinement pass + post-processing | "
                          "sampling + solve on three streams (default), 2 = match | sampling + solve")
-    ap.set_defaults(pipeline=None)  # None: two streams for one-scene workloads, one stream per scene for the three-scene pyramid workload
+    ap.set_defaults(pipeline=None)  # None: the staged arrangement for one-scene workloads, one stream per scene for the three-scene pyramid workload
                                     # (six streams slow it down: 6.8 k -> 5.5 k pairs/s, round 3)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-launcher", action="store_true",
@@ -246,10 +246,9 @@ class SceneRunner:
     * Inside a scene the batch goes through two stages on two streams: `match` (both passes of the coarse-to-fine loop: chip-wide
       launches) and `finish` (sampling + solve: a third of its time is one-workgroup-per-pair kernels -- curve sort, radix select,
       LM finish -- on 32 of 256 CUs).  A step's finish waits for its own match only, so it runs under the NEXT step's match: the
-      way a stream of batches goes through the path in deployment (448b32: 3.53 -> 3.19 ms per step).  OFF for the timed region
-      of the driver's line: the overlapped kernels take CUs from the roofline op while it is being timed (96.5 -> 107 us), and
-      six streams slow the three-scene workload down; the default single-GPU 448b32 run reports it as `pipelined_steps` instead
-      (a secondary leg after the timed region, like `with_conv_stacks`); --pipeline puts it into the timed region.
+      way a stream of batches goes through the path in deployment (448b32: 3.53 -> 3.19 ms per step; --stages 2).  The roofline
+      op is timed in separate one-stream steps (the overlapped kernels take CUs from it: 96.5 -> 107 us), and the three-scene
+      workload keeps one stream per scene (four hardware queues; six streams slow it down).
     * Round 4, one-scene workloads: THREE stages on three streams -- first pass | refinement pass + post-processing | sampling + solve
       (GFNet.match_first_pass / match_second_pass): step k + 1's first pass runs beside step k's refinement pass, and every kernel
       still sees the whole batch.  The heavy kernels fill a CU's register file, so the overlap is workgroup by workgroup -- a
