@@ -17,7 +17,8 @@ from gfnet_amd._synthetic import WORKLOADS, Scene  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 wl = WORKLOADS["pyr-fp16"]
 dev = torch.device("cuda", 0)
-pool = parallel.concurrent_streams(4)
+NQ = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+pool = parallel.concurrent_streams(6 if NQ >= 8 else 4)
 
 
 def scenes():
@@ -56,3 +57,16 @@ with torch.inference_mode():
     timed("C  672 in three stages (224 behind its first stage) | 448", lambda: (s672.replay_pipelined(), s224.replay(), s448.replay()))
     del s224, s448
     timed("   672 alone in three stages", lambda: s672.replay_pipelined())
+    if NQ >= 8:
+        del s672
+        s224, s448, s672 = scenes()
+        s224.capture(0, stream=pool[5])
+        s448.capture_pipelined(0, streams=(pool[3], pool[4]))
+        s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
+        timed("D  672 in three stages | 448 in two | 224 (six streams, GPU_MAX_HW_QUEUES=8)", lambda: (s672.replay_pipelined(), s448.replay_pipelined(), s224.replay()))
+        del s224, s448, s672
+        s224, s448, s672 = scenes()
+        s224.capture(0, stream=pool[4])
+        s448.capture(0, stream=pool[3])
+        s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
+        timed("E  672 in three stages | 448 | 224 (five streams)", lambda: (s672.replay_pipelined(), s448.replay(), s224.replay()))
