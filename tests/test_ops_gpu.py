@@ -323,6 +323,27 @@ def test_weighted_grid_dlt_matches_oracle():
     assert _ace(Ho1[0], host(H1)[0]) < 1e-3
 
 
+@pytest.mark.parametrize("B,c,hs,G,r,Dd", [(3, 16, 84, 48, 2, 16), (2, 32, 112, 64, 4, 32), (3, 32, 70, 80, 4, 8), (1, 8, 90, 50, 0, 8),
+                                            (5, 8, 150, 96, 0, 8), (2, 16, 100, 47, 2, 16)])
+def test_banded_block_order_of_symmetric_batches_changes_nothing(B, c, hs, G, r, Dd):
+    """Round 4: symmetric batches with >= 8 cell blocks per direction launch refiner_input's blocks in XCD-banded order (a 1-D grid:
+    an XCD takes one band of both directions of a pair; bands of unequal length rotate with the pair, spare slots return at once).
+    The concatenated batch -- same maps, not symmetric -- takes the plain 2-D launch: every plane of `d`, the local correlation
+    behind the fused plan included, is bit-identical.  Block counts 9, 16, 25, 10 (ragged last block), 36, 9; odd pair counts."""
+    from gfnet_amd import ops
+
+    a = synth.lattice_normalish((B, c, hs, hs), 311)
+    b = synth.lattice_normalish((B, c, hs, hs), 312)
+    flow = np.concatenate((synth.homography_flow(B, G, 313), synth.homography_flow(B, G, 314, scale=0.95)))
+    w = synth.lattice_uniform((Dd, 2, 1, 1), 315)
+    bias = synth.lattice_uniform((Dd,), 316)
+    kw = dict(corr_in_other=r > 0)
+    d_sym = ops.refiner_input(G, dev(a), dev(b), dev(flow), dev(w), dev(bias), r, **kw)
+    d_cat = ops.refiner_input(G, dev(np.concatenate((a, b))), dev(np.concatenate((b, a))), dev(flow), dev(w), dev(bias), r, **kw)
+    np.testing.assert_array_equal(host(d_sym), host(d_cat))
+    assert_close(host(d_sym), oracle.refiner_input(G, np.concatenate((a, b)), np.concatenate((b, a)), flow, w, bias, r, **kw), TOL, "d")
+
+
 # ---- symmetric batches without the reference's concatenated pyramid copies (network.py:213-222) ----
 def test_symmetric_virtual_batch_equals_concatenated_batch():
     from gfnet_amd import ops
