@@ -2,7 +2,10 @@
    python tools/probe_graph_layouts.py [steps]
    A: one graph per scene, the largest scene in two stages (4 streams)        -- bench.py's layout
    B: the largest scene in three stages, the two small scenes one after the other on the fourth stream
-   C: the largest scene in three stages, the middle scene on the fourth stream, the small scene behind the largest's first stage"""
+   C: the largest scene in three stages, the middle scene on the fourth stream, the small scene behind the largest's first stage
+   F: as C with the small scene behind the largest's sampling + solve stage
+   G: the two larger scenes in two stages each, the small scene behind the middle scene's second stage
+   (measured: A 8.5 k pairs/s, B 6.6 k, C 7.5 k, F 7.7-7.8 k, G 7.9 k; the 672 scene alone 1.99 ms in two stages, 1.68 ms in three)"""
 import os
 import sys
 import time
@@ -55,8 +58,21 @@ with torch.inference_mode():
     s448.capture(0, stream=pool[3])
     s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
     timed("C  672 in three stages (224 behind its first stage) | 448", lambda: (s672.replay_pipelined(), s224.replay(), s448.replay()))
+    del s224, s448, s672
+    s224, s448, s672 = scenes()
+    s224.capture(0, stream=pool[2])
+    s448.capture(0, stream=pool[3])
+    s672.capture_pipelined(0, streams=(pool[0], pool[1], pool[2]), stages=3)
+    timed("F  672 in three stages (224 behind its sampling + solve) | 448", lambda: (s672.replay_pipelined(), s224.replay(), s448.replay()))
+    timed("F' the same, 224 enqueued first", lambda: (s224.replay(), s672.replay_pipelined(), s448.replay()))
+    del s224, s448, s672
+    s224, s448, s672 = scenes()
+    s224.capture(0, stream=pool[3])
+    s448.capture_pipelined(0, streams=(pool[2], pool[3]))
+    s672.capture_pipelined(0, streams=(pool[0], pool[1]))
+    timed("G  672 in two stages | 448 in two stages (224 behind its sampling + solve)", lambda: (s672.replay_pipelined(), s448.replay_pipelined(), s224.replay()))
     del s224, s448
-    timed("   672 alone in three stages", lambda: s672.replay_pipelined())
+    timed("   672 alone in two stages", lambda: s672.replay_pipelined())
     if NQ >= 8:
         del s672
         s224, s448, s672 = scenes()
