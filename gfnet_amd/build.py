@@ -66,25 +66,19 @@ def build_ablate(verbose=False):
     return out
 
 
-def build_mm(verbose=False):
-    """The parked r = 3 / 4 matrix-core local-correlation kernel (csrc/local_corr_mw.h: four waves per workgroup, a wave per group;
-    -DGFN_MM_DEFAULT=2 would build the persistent kernel of csrc/local_corr_mm.h instead) as a library of its own, libgfnet_hip_mm.so:
-    local_corr.hip compiled with -DGFN_MM_DEFAULT=1, every other object shared with the product library.  Not the product path;
-    tests/test_local_corr_mm_gpu.py keeps its parity claim checkable."""
-    src = os.path.join(CSRC, "local_corr.hip")
-    obj = os.path.join(CSRC, "local_corr_mm.o")
-    out = os.path.join(CSRC, "libgfnet_hip_mm.so")
-    if _stale(obj, _deps(src)):
-        cmd = [HIPCC] + FLAGS + ["-DGFN_MM_DEFAULT=1", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-    others = [s[:-4] + ".o" for s in sources() if not s.endswith("local_corr.hip")]
-    if _stale(out, [obj] + others):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, obj] + others
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+def build_variant(name, flags, src_name="local_corr.hip", verbose=False):
+    """A/B builds (tools/ab_lean.py): csrc/libgfnet_hip_<name>.so = the product objects with ONE source recompiled with extra flags.
+    Not the product path."""
+    build(verbose=verbose)
+    src = os.path.join(CSRC, src_name)
+    obj = os.path.join(CSRC, f"{src_name[:-4]}_{name}.o")
+    out = os.path.join(CSRC, f"libgfnet_hip_{name}.so")
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src_name, []) + list(flags) + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    others = [s[:-4] + ".o" for s in sources() if not s.endswith(src_name)]
+    subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, obj] + others, check=True)
     return out
 
 
@@ -110,9 +104,10 @@ if __name__ == "__main__":
     if "--ablate" in sys.argv:
         print(build_ablate(verbose=True))
         sys.exit(0)
-    if "--mm" in sys.argv:
-        build(verbose=True)
-        print(build_mm(verbose=True))
+    if "--variant" in sys.argv:  # python -m gfnet_amd.build --variant NAME [--src file.hip] -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        src_name = sys.argv[sys.argv.index("--src") + 1] if "--src" in sys.argv else "local_corr.hip"
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-m")], src_name, verbose=True))
         sys.exit(0)
     extra = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
     print(build(force="--force" in sys.argv, verbose=True, extra=extra))

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/gfnet_hip.h"
 
@@ -14,6 +15,18 @@ namespace gfn {
 
 char *last_error_buf();  // thread-local, 512 bytes
 int fail(int code, const char *fmt, ...);
+
+// Experiment switches (GFN_CONV_*, GFN_KDE_* environment variables read by tools/): only the -DGFN_ABLATE build
+// (python -m gfnet_amd.build --ablate -> libgfnet_hip_ablate.so) looks at the environment; in the product library the environment
+// cannot change which kernel runs.
+inline const char *exp_env(const char *name) {
+#ifdef GFN_ABLATE
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256 * NS, NS == 1 ? 2 : 1) void dwpw_fused_kernel(c
 
 // GFN_CONV_TPB (environment, experiments): work items per workgroup of the fused kernel, 0 = heuristic
 static int g_conv_tpb = [] {
-    const char *e = getenv("GFN_CONV_TPB");
+    const char *e = gfn::exp_env("GFN_CONV_TPB");
     return e ? atoi(e) : 0;
 }();
 
@@ -617,7 +617,7 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
 template <int TW, bool F16, bool HIN = false, bool HOUT = false, bool MM = false, int KW = 1>
 int launch_fused(const float *x, const float *packed, float *y, int B, int M, int K, int G, int dbg, hipStream_t s) {
     const int tiles = (M + 31) / 32;
-    static const bool nb1 = getenv("GFN_CONV_NB1") != nullptr;  // experiments: 128-cell tiles for the narrow blocks too
+    static const bool nb1 = gfn::exp_env("GFN_CONV_NB1") != nullptr;  // experiments: 128-cell tiles for the narrow blocks too
     if (F16 && tiles <= 3 && TW >= 16 && G % (2 * kBN / TW) == 0 && !nb1) {  // fp32: the larger tiles cost a resident workgroup (LDS)
         if constexpr (F16 && TW >= 16) {
             switch (tiles) {
@@ -627,7 +627,7 @@ int launch_fused(const float *x, const float *packed, float *y, int B, int M, in
             }
         }
     }
-    static const bool ns1 = getenv("GFN_CONV_NS1") != nullptr;  // experiments: one slab per workgroup, two workgroups per cell tile
+    static const bool ns1 = gfn::exp_env("GFN_CONV_NS1") != nullptr;  // experiments: one slab per workgroup, two workgroups per cell tile
     if (tiles <= 7 || ns1) {
         switch (tiles) {
             case 1: return launch_fused_mt<1, TW, 1, F16, 1, HIN, HOUT, MM>(x, packed, y, B, M, K, G, dbg, s);

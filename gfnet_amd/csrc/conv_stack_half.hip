@@ -11,11 +11,11 @@
 namespace {
 
 // GFN_CONV_VALU_DW (environment, experiments): the depthwise on the VALU (fp32 taps) instead of the matrix core
-static const bool g_valu_dw = getenv("GFN_CONV_VALU_DW") != nullptr;
-static const int g_tw16_min = getenv("GFN_CONV_TW16_MIN") ? atoi(getenv("GFN_CONV_TW16_MIN")) : 0;
+static const bool g_valu_dw = gfn::exp_env("GFN_CONV_VALU_DW") != nullptr;
+static const int g_tw16_min = gfn::exp_env("GFN_CONV_TW16_MIN") ? atoi(gfn::exp_env("GFN_CONV_TW16_MIN")) : 0;
 
 // GFN_CONV_KW1: one K tile per iteration for the wide blocks too (experiments)
-static const bool g_kw1 = getenv("GFN_CONV_KW1") != nullptr;
+static const bool g_kw1 = gfn::exp_env("GFN_CONV_KW1") != nullptr;
 
 template <bool HIN, bool HOUT, bool MM>
 int launch_half(const void *x, const float *packed, void *y, int B, int C, int M, int G, int dbg, hipStream_t s) {

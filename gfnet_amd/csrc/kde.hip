@@ -696,10 +696,10 @@ GFN_EXPORT int gfn_kde_density_sorted(const float *x, const float *y, float *out
         while (blocks * MS < 2048 && nblk / (MS * 2) >= 8 && MS < 32) MS *= 2;
     }
     float *dst = (MS > 1 || perm) ? part : out;  // perm: results leave through the combine kernel, in the caller's order
-    static const bool valu_only = getenv("GFN_KDE_VALU") != nullptr;  // experiments: the difference-form kernel
-    static const bool no_sym = getenv("GFN_KDE_NOSYM") != nullptr;    // experiments: full N x N evaluation
+    static const bool valu_only = gfn::exp_env("GFN_KDE_VALU") != nullptr;  // experiments: the difference-form kernel
+    static const bool no_sym = gfn::exp_env("GFN_KDE_NOSYM") != nullptr;    // experiments: full N x N evaluation
     const bool sym = x == y && N == M && !no_sym;
-    static const int tile_cull = getenv("GFN_KDE_NOTILE") == nullptr;  // experiments: 0 = cull per block only
+    static const int tile_cull = gfn::exp_env("GFN_KDE_NOTILE") == nullptr;  // experiments: 0 = cull per block only
     if (valu_only) {
         hipLaunchKernelGGL(kde4_culled_kernel, dim3((N + kKdeThreads - 1) / kKdeThreads, MS, Bt), dim3(kKdeThreads), 0, s, xs, ys,
                            box, dst, N, Mp);

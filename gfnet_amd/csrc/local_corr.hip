@@ -70,7 +70,6 @@ struct LcParams {
     int *todo;                        // [kTodoHdr + B*tiles]: header (see kTodoHdr), then the ids of the tiles left to the second launch
     long todo_ints;
     int planned;                      // lean path: the plan is already in scratch (gfn_refiner_input_plan_fwd_dt wrote it)
-    int mm;                           // the plan is for / the tiles go to the matrix-core kernel (local_corr_mm.h) where Lean<R>::kMM
     int mq;                           // r >= 5: the first launch is the matrix-core tile kernel (local_corr_mq.h)
     int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
@@ -863,11 +862,8 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 }
 
 #include "local_corr_lean.h"
-#include "local_corr_mm.h"
+#include "local_corr_mstage.h"
 #include "local_corr_mq.h"
-#if GFN_MM_DEFAULT == 1
-#include "local_corr_mw.h"
-#endif
 
 // shapes the lean tile path takes (it keeps at most 8 channels of the f0 block per wave in registers, addresses planes with
 // 32-bit byte offsets, and reads fp16 quads at 4-byte alignment)
@@ -890,16 +886,6 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
 #endif
     }
     return true;
-}
-
-// shapes whose default path is the matrix-core kernel (local_corr_mm.h)
-bool mm_shape(int C, int H, int W, int G, int r, int f16) {
-    const bool kmm = GFN_MM_DEFAULT != 0 && (r == 3 || r == 4);  // == Lean<r>::kMM (r = 6, 7 were measured slower still and spill)
-    const long K = (long)(2 * r + 1) * (2 * r + 1);
-    // (one channel count per radius is built: GFNet's r = 4 on 32-channel maps, and r = 3 on 16 for the tests -- every further
-    // instantiation of the persistent kernel costs ~40 s of compile time)
-    // (fp32 maps only: the fp16 instantiations doubled the library's four-minute compile for a parked kernel; fp16 maps take the lean path)
-    return kmm && C == (r == 4 ? 32 : 16) && !f16 && (long)C * H * W < (1L << 30) && K * G * G < (1L << 30) && (long)C * G * G < (1L << 30);
 }
 
 // large windows on 64-channel maps: the matrix-core tile kernel of local_corr_mq.h is the first launch (byte offsets into the maps and
@@ -943,13 +929,14 @@ int device_cu_count() {
 }
 
 template <int R, int NCH, typename FT>
-void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, unsigned flags) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)flags;
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
 
-// the matrix-core path (local_corr_mm.h): plan (unless the refiner-input launch wrote it), the persistent tile kernel (one 16-wave
-// workgroup per CU), and the round-1 sub-tile routine for the tiles the plan listed (4 x 16-cell tiles re-cut into 4 x 8 halves)
+// the round-1 tile path: the staged tile kernel (r >= 5 on 64-channel maps: the matrix-core kernel of local_corr_mq.h) and the second
+// launch for the tiles it listed
 template <int R, int ROUNDS, typename FT, bool QOK>
 int launch_tiles_staged(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
     // per call and unconditional: the attribute is per device, a process may drive several
@@ -977,53 +964,6 @@ int launch_tiles_staged(const LcParams &p, unsigned total, size_t lds, hipStream
     return gfn::check_launch("local_corr_irregular_kernel");
 }
 
-template <int R, typename FT>
-int launch_mm(const LcParams &p0, hipStream_t stream) {
-    LcParams p = p0;
-    lean_window_params<R>(p);
-    const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
-    if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    if (!p.planned) {
-        hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
-        if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
-    }
-#if GFN_MM_DEFAULT == 1
-    // the four-wave kernel of local_corr_mw.h: one workgroup per tile
-#define GFN_MW_LAUNCH(CC)                                                                                                                  \
-    do {                                                                                                                                   \
-        constexpr int lds_mw = Mw<R, CC>::kLds;                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mw_kernel<R, CC, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  lds_mw);                                                                                                 \
-        hipLaunchKernelGGL((local_corr_mw_kernel<R, CC, FT>), dim3(total), dim3(kMwThreads), lds_mw, stream, p);                           \
-    } while (0)
-    if constexpr (R == 4) GFN_MW_LAUNCH(32);
-    else GFN_MW_LAUNCH(16);
-#undef GFN_MW_LAUNCH
-    if (int e = gfn::check_launch("local_corr_mw_kernel")) return e;
-#else
-    const unsigned cus = (unsigned)device_cu_count();
-    const dim3 grid(total < cus ? total : cus);
-#define GFN_MM_LAUNCH(CC)                                                                                                                  \
-    do {                                                                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_mm1_kernel<R, CC, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  kMmLds);                                                                                                 \
-        hipLaunchKernelGGL((local_corr_mm1_kernel<R, CC, FT>), grid, dim3(kMmThreads), kMmLds, stream, p);                                 \
-    } while (0)
-    if constexpr (R == 4) GFN_MM_LAUNCH(32);  // mm_shape: one channel count per radius
-    else GFN_MM_LAUNCH(16);
-#undef GFN_MM_LAUNCH
-    if (int e = gfn::check_launch("local_corr_mm1_kernel")) return e;
-#endif
-    constexpr int NC = 64;
-    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
-                       (size_t)NC * (p.C + 4) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, 2, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kMaxLds);
-    const unsigned grid2 = total < 256 ? total : 256;
-    hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
-    return gfn::check_launch("local_corr_irregular_kernel");
-}
-
 // the lean path (local_corr_lean.h): plan (unless the refiner-input launch wrote it), the tile kernel, and for r <= 2 the separate
 // second launch (r >= 3: the tile kernel's first workgroups are the second launch)
 template <int R, typename FT>
@@ -1033,34 +973,40 @@ int launch_lean_path(const LcParams &p0, hipStream_t stream) {
     constexpr int NC = 64;
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) +
+    const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + (((NC * (2 * (2 * R + 1) + 1) + 16) * 4 + 15) & ~15) +  // + 16: the table's skew (lean_tile)
                         (size_t)NC * ((Lean<R>::kF0Chunk ? kChunk : p.C) + 4) * 4;
     if (lds2 > kMaxLds) return -1000;
     if (!p.planned) {
         hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
         if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
     }
-    switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-        case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
-        case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
-        default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
-    }
-    if (int e = gfn::check_launch("local_corr_tile2_kernel")) return e;
-    if (lean_workers<R>() > 0) return GFN_OK;  // its first workgroups are the second launch
-    const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
-                       (size_t)NC * (p.C + 4) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, 2, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kMaxLds);
-    const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
-    hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
-    return gfn::check_launch("local_corr_irregular_kernel");
+    auto tiles = [&](unsigned flags) {
+        switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
+            case 16: launch_lean<R, 1, FT>(p, total, lds2, stream, flags); break;
+            case 32: launch_lean<R, 2, FT>(p, total, lds2, stream, flags); break;
+            default: launch_lean<R, 4, FT>(p, total, lds2, stream, flags); break;
+        }
+        return gfn::check_launch("local_corr_tile2_kernel");
+    };
+    auto second = [&]() {
+        const size_t lds = kStageBytes + ((NC * 20 + 32 + 15) & ~15) + (R <= 2 ? ((NC * (2 * (2 * R + 1) + 1) * 4 + 15) & ~15) : 0) +
+                           (size_t)NC * (p.C + 4) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_irregular_kernel<R, 2, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kMaxLds);
+        const unsigned grid2 = total < 256 ? total : 256;  // one per CU: with nothing on the list (the common case) the launch is pure overhead
+        hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
+        return gfn::check_launch("local_corr_irregular_kernel");
+    };
+    if (lean_workers<R>() > 0) return tiles(0);  // its first workgroups are the second launch
+    // (Round 5: marking the tile kernel hipExtAnyOrderLaunch behind a second launch issued first -- the two are independent, the plan
+    // launch wrote the list -- does not make them run side by side on gfx950: 107.2 vs 108.5 us with three tiles listed, the flag is
+    // documented as unsupported on GFX9.)
+    if (int e = tiles(0)) return e;
+    return second();
 }
 
 template <int R, int ROUNDS, typename FT>
 int launch_tile(const LcParams &p0, hipStream_t stream, bool lean) {
-    if constexpr (Lean<R>::kMM && sizeof(FT) == 4) {
-        if (lean && p0.mm) return launch_mm<R, FT>(p0, stream);
-    }
 #if defined(GFN_LEAN_R7) && GFN_LEAN_R7
     constexpr bool kLeanBuilt = true;
 #else
@@ -1159,17 +1105,16 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
 #endif
 
     // the tiled path needs the tile list in scratch; without it the general kernel still gives the right answer
-    // variant 0: the tiled path (lean tile kernel for r <= 4, its D-stage on the matrix core where Lean<R>::kMM); 1: general
+    // variant 0: the tiled path (lean fp32 tile kernel for r <= 4, the matrix-core kernel for r >= 5 on 64-channel maps); 1: general
     // kernel; 2: the round-1 tile kernel for every radius; 4: the lean tile kernel with the round-2 fp32 FMA D-stage (bit-identical
-    // to variant 2; kept as the cross-check of the matrix-core kernel)
+    // to variant 2; the fp32 cross-check / opt-out of the r >= 5 matrix-core kernel)
     const bool planned = (variant & 8) != 0;  // gfn_refiner_input_plan_fwd_dt has already written this call's plan
     variant &= ~8;
     const bool want_mm = variant == 0;
     if (variant == 4) variant = 0;
     const bool tiled = variant == 0 && flow && !grid_based && win_h == H && win_w == W;
-    p.mm = (want_mm && tiled && mm_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
     p.mq = (want_mm && tiled && mq_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
-    bool lean = tiled && (p.mm || lean_shape(C, H, W, G, r, p.f16));
+    bool lean = tiled && lean_shape(C, H, W, G, r, p.f16);
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
     p.planned = planned ? 1 : 0;
     if (lean && scratch) {
@@ -1220,7 +1165,7 @@ GFN_EXPORT int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f
 
 // ---- refiner input + plan in one launch ----------------------------------------------------------------------------------
 GFN_EXPORT int gfn_local_corr_plans(int C, int H, int W, int G, int r, int f1_dtype) {
-    return (lean_shape(C, H, W, G, r, f1_dtype == GFN_F16) || mm_shape(C, H, W, G, r, f1_dtype == GFN_F16)) ? 1 : 0;
+    return lean_shape(C, H, W, G, r, f1_dtype == GFN_F16) ? 1 : 0;
 }
 
 namespace {
@@ -1247,7 +1192,7 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     if (B < 0 || C <= 0 || Hs <= 0 || Ws <= 0 || G <= 0 || disp_dim < 0 || d_bs < (int64_t)(2 * C + disp_dim) * G * G || ((symmetric & 1) && (B & 1)) ||
         (symmetric & ~3) || (long)C * Hs * Ws >= (1L << 31) || B > 65535 || (long)G * G >= (1L << 31))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: bad size");
-    if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16) && !mm_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
+    if (!lean_shape(C, Hs, Ws, G, r, dtype == GFN_F16))
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input_plan: the local correlation of this shape takes no plan (ask gfn_local_corr_plans first)");
     if (!scratch || scratch_bytes < gfn_local_corr_scratch_bytes(B, G) || ((uintptr_t)scratch & 3))
         return gfn::fail(GFN_ERR_SCRATCH, "refiner_input_plan: scratch too small");
@@ -1261,7 +1206,6 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
     p.todo = reinterpret_cast<int *>(scratch);
     p.plan = lean_plan_ptr(scratch, B, G);
-    p.mm = mm_shape(C, Hs, Ws, G, r, dtype == GFN_F16) ? 1 : 0;  // the plan is for the default path of the call that follows (variant 8)
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == GFN_F16;
     switch (r) {

@@ -23,13 +23,8 @@
 //   * tile = two 4 x 8-cell halves (cells 0-31 / 32-63), the epilogue still stores 64-byte row segments;
 //   * fraction table: lane = cell, wave = tap index (no division); stores use scalar plane offsets.
 
-constexpr int kMwRows = 16;  // local_corr_mw.h (GFN_MM_DEFAULT == 1): a group's box is at most kMwRows rows high
-constexpr int kMmNBW = 10;  // local_corr_mm.h: accumulator blocks per wave of the matrix-core kernel (a group's box: <= 2 kMmNBW rows)
-template <int R> __device__ __forceinline__ bool mm_region_fits_rt(int w, int h, int C);  // local_corr_mm.h
+constexpr int kMmNBW = 10;  // local_corr_mq.h: accumulator blocks per wave of the matrix-core kernel (a group's box: <= 2 kMmNBW rows)
 
-#ifndef GFN_MM_DEFAULT
-#define GFN_MM_DEFAULT 0
-#endif
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
@@ -54,15 +49,12 @@ template <int R>
 struct Lean {
     // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU.  r = 7: the D buffer that aliases the stage (64 cells x 257
     // floats) needs 65 792 bytes; with the f0 block staged chunk by chunk (kF0Chunk) the total stays at 80 160
-    static constexpr int kDbuf = (64 * ((2 * R + 2) * (2 * R + 2) + 1) * 4 + 15) & ~15;
+    static constexpr int kDbuf = ((64 * ((2 * R + 2) * (2 * R + 2) + 1) + 16) * 4 + 15) & ~15;  // + 16: the skew of cells 32-63 (lean_tile)
     static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : (kDbuf > 64 * 1024 ? kDbuf : 64 * 1024);
     static constexpr bool kF0Chunk = R >= 5;  // 64-channel maps: 16 channels of the f0 block in LDS at a time (5 KB instead of 17)
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
-    // R >= 5 (GFNet: r = 6, 7 on 64-channel maps, 196 / 256 products per cell and channel): the matrix-core kernel is the default
-    // path; R = 3, 4 only in GFN_MM_DEFAULT builds (there the lean fp32 kernel, two workgroups per CU, is still faster)
-    static constexpr bool kMM = GFN_MM_DEFAULT && (R == 3 || R == 4);  // the default path of these radii is the matrix-core kernel (local_corr_mm.h)
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
@@ -154,7 +146,6 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
         // of the tile (their union)
         const int rx0 = row_min_i32(c.bx0), ry0 = row_min_i32(c.by0), rx1 = row_min_i32(-c.bx1), ry1 = row_min_i32(-c.by1);
         int hx0[2], hy0[2], hx1[2], hy1[2];
-        bool mm_ok = true;  // matrix-core kernel: every group's box fits two 16-position column tiles x 2 kMmNBW rows (its accumulators)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             int gx0[2], gy0[2], gx1[2], gy1[2];
@@ -165,7 +156,6 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 gy0[k] = __builtin_amdgcn_readlane(ry0, l15);
                 gx1[k] = -__builtin_amdgcn_readlane(rx1, l15);
                 gy1[k] = -__builtin_amdgcn_readlane(ry1, l15);
-                if (Lean<R>::kMM && p.mm && gx0[k] != kFar) mm_ok &= (gx1[k] - gx0[k] <= 32) & (gy1[k] - gy0[k] <= (GFN_MM_DEFAULT == 1 ? kMwRows : 2 * kMmNBW));
             }
             hx0[h] = min(gx0[0], gx0[1]); hy0[h] = min(gy0[0], gy0[1]);
             hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
@@ -191,22 +181,6 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
                 return region_fits<R>(u);
             };
-            if (Lean<R>::kMM && p.mm) {
-                // the matrix-core kernel's plan: ONE region (its stage holds ~1100 positions: no halves mode), the same start
-                // alignment rule, no pitch padding (its slots are swizzled); what does not fit goes to the second launch's list
-                const int bx0 = min(hx0[0], hx0[1]), by0 = min(hy0[0], hy0[1]), bx1 = max(hx1[0], hx1[1]), by1 = max(hy1[0], hy1[1]);
-                int x0 = p.f16 ? (bx0 & ~1) : bx0;
-                const int xa = bx0 & ~3;
-                if (!all_in || ((p.W & 3) == 0 && ((bx1 - xa + 3) >> 2) == ((bx1 - bx0 + 3) >> 2))) x0 = xa;
-                int w = max(bx1 - x0, 0), h = max(by1 - by0, 0), y0 = by0;
-                if (w == 0 || h == 0) { x0 = 0; y0 = 0; w = 0; h = 0; }
-                const bool fits = mm_ok && mm_region_fits_rt<R>(w, h, p.C);
-                const int flags = (all_in ? kPlanInterior : 0) | (fits ? 0 : kPlanSecond);
-                reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid] = make_int4(x0, y0, (h << 16) | w, flags);
-                reinterpret_cast<int4 *>(p.plan)[kPlanV4 * wid + 1] = make_int4(0, 0, 0, 0);
-                if (!fits) p.todo[kTodoHdr + atomicAdd(p.todo, 1)] = (int)wid;
-                continue;
-            }
             RowPlan ua, ub;
             const bool border_ok = true;
             int flags = all_in ? kPlanInterior : 0;
@@ -293,9 +267,13 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
     constexpr int D = 2 * R + 1, K = D * D;
     constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
+    // Round 5: the epilogue's lanes 0-31 hold cells c and c + 32 (lane -> cell so that a wave stores whole grid-row segments), whose D
+    // and table rows start 32 DS / 32 TS dwords apart = on the same bank: every epilogue read was a 2-way conflict.  Rows of cells
+    // 32-63 are skewed by 16 dwords.
+    constexpr int kSkew = 16;
     constexpr bool F0CH = Lean<R>::kF0Chunk;       // the f0 block goes through LDS one 16-channel chunk at a time
     constexpr int CS = (F0CH ? kChunk : C) + 4;
-    static_assert(NC * DS * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
+    static_assert((NC * DS + kSkew) * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
 
     float4 *s4 = reinterpret_cast<float4 *>(smem);
     float *dbuf = reinterpret_cast<float *>(smem);
@@ -306,7 +284,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     int *cellFlag = reinterpret_cast<int *>(cellNy + NC);     // kCellSlow: redo per tap; kCellEmpty: window misses the image, result 0
     int *hdr = cellFlag + NC;                                  // [4]: number of flagged cells
     constexpr int kCellBytes = (NC * 20 + 32 + 15) & ~15;
-    constexpr int kTabBytes = (NC * TS * 4 + 15) & ~15;
+    constexpr int kTabBytes = ((NC * TS + kSkew) * 4 + 15) & ~15;
     float *tab = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);   // [NC][TS] per-tap fractions
     float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + kTabBytes);  // [NC][C + 4]: the tile's f0, cell-major
 
@@ -344,11 +322,17 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     const int fk = lane >> 4, fr = (lane & 15) >> 2, fqd = lane & 3;
     const bool f0_lane = fk < (NF0 < 4 ? NF0 : 4);
     const rsrc_t f0r = make_rsrc(p.f0 + (size_t)b * p.f0_bs, (unsigned)C * GG4);
+    // Round 5: where the f0 block is filed.  A wave's lanes hold (channel fk, tile row fr, column quad fqd); with rows of C + 4 floats
+    // (16-byte aligned for the D-stage's float4 reads) tile row and column half do not reach the bank index, and with a wave's channels
+    // 8 apart neither did the channel's low bits: the 32 lanes of a ds_write_b32 pass hit 4 banks (8-way conflict, 16 cycles per store
+    // instead of 2).  Now a wave takes NF0 CONSECUTIVE channels and the row of cell c is c ^ (tile row of c) -- the tile row XORed into
+    // the column's low bits: 16 banks per pass (2-way: free for 4-byte stores).  The D-stage reads row f0_row(cell).
+    auto f0_row = [](int cell) { return cell ^ ((cell >> 3) & 3); };
     auto f0_issue = [&](int c0) {   // c0: first channel of the chunk (0 when the whole block is staged at once)
         const bool in = f0_lane & (row0 + fr < G) & (col0 + 4 * fqd < G);
 #pragma unroll
         for (int l = 0; l < NF0L; ++l) {
-            const int ch = c0 + wave + (4 * l + fk) * kWaves;
+            const int ch = c0 + wave * NF0 + 4 * l + fk;
             const unsigned fgoff = in ? (unsigned)((row0 + fr) * G + col0 + 4 * fqd) * 4u + (unsigned)ch * GG4 : 0u;
             f0q[l] = buf_ld4(f0r, fgoff, 0u);
         }
@@ -357,13 +341,13 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (f0_lane) {
 #pragma unroll
             for (int l = 0; l < NF0L; ++l) {
-                const int ch = wave + (4 * l + fk) * kWaves;   // channel inside what f0s holds
+                const int ch = wave * NF0 + 4 * l + fk;   // channel inside what f0s holds
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int fc = 4 * fqd + e;
                     const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
                     const bool fok = (row0 + fr < G) & (col0 + fc < G);
-                    f0s[fcell * CS + ch] = fok ? f0q[l][e] : 0.f;
+                    f0s[f0_row(fcell) * CS + ch] = fok ? f0q[l][e] : 0.f;
                 }
             }
         }
@@ -416,7 +400,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
                 const int origin = isy ? cY0 : cX0;
                 // tap k must start at patch column/row k; if rounding moved its floor(), redo the cell per tap
                 tab_bad |= (origin != kFar) & !(fl == (float)(origin + k));
-                tab[lane * TS + a] = pix - fl;
+                tab[lane * TS + (lane >> 5) * kSkew + a] = pix - fl;
             }
         }
         return tab_bad;
@@ -426,7 +410,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     int g, s16;
     lane_group(lane, g, s16);
     const int cr = wave * 4 + g;  // cell inside a half (0..31)
-    unsigned apk[ROUNDS][(NP + 1) / 2];
+    // Round 5: one register per (round, pass) holding the BYTE address of the position's slot (ds_read_b128 takes it as it is, the
+    // four float4s of a slot through the instruction's offset field).  Rounds 2-4 packed two float4 indices per register because the
+    // kernel sat at 128 VGPRs with the second-launch worker inlined; unpacking cost a v_and / v_bfe + v_lshl_add per position and
+    // chunk (~65 of a wave's ~1 030 vector instructions at r = 4).  -DGFN_LEAN_APK=1: the packed form.
+#ifndef GFN_LEAN_APK
+#define GFN_LEAN_APK 0
+#endif
+    constexpr bool kApk = GFN_LEAN_APK != 0;
+    unsigned apk[ROUNDS][kApk ? (NP + 1) / 2 : NP];
     auto addressing = [&](int rd, int X0, int Y0) {
         const RowPlan &u = (HALVES && rd == 1) ? uB : uA;
         // cells without a patch (off the grid, flagged, empty) read slot 0 onwards: valid memory, result unused
@@ -438,7 +430,9 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             int slot = base + yy * u.pitch + xx;
             if (16 * t + 15 >= P) slot = pp < P ? slot : 0;  // positions past the patch (last pass only)
             const unsigned a = (unsigned)(slot * kSlotV4);
-            if (t & 1)
+            if (!kApk)
+                apk[rd][t] = a * 16u;
+            else if (t & 1)
                 apk[rd][t >> 1] |= a << 16;
             else
                 apk[rd][t >> 1] = a;
@@ -461,8 +455,16 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     STAMP(3);
     __syncthreads();
     STAMP(4);
-    if (!kFlowAll && !ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
-    if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    // Round 5 experiment: the fraction table is only read by the epilogue; filled behind the main loop (-DGFN_LEAN_TABLE_LATE=1) it is
+    // out of the chain barrier -> addressing -> first product and runs beside the other waves' D-stages
+#ifndef GFN_LEAN_TABLE_LATE
+#define GFN_LEAN_TABLE_LATE 0  // measured level (r = 4: 96.5 vs 96.3 us, r = 2: 150.3 vs 153.9): the tile kernels are bound by what they issue, not by where in the tile it sits
+#endif
+    constexpr bool kTableLate = GFN_LEAN_TABLE_LATE != 0 && !kFlowAll;
+    if (!kTableLate) {
+        if (!kFlowAll && !ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+        if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    }
 
     if (!kFlowAll) {
 #pragma unroll
@@ -490,7 +492,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-            for (int h = 0; h < (NP + 1) / 2; ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the packed indices packed
+            for (int h = 0; h < (kApk ? (NP + 1) / 2 : NP); ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the (packed) addresses as they are: no recomputation per chunk
         if (more && !ABL(p, 1)) {  // next step's loads: in flight across this D-stage
             quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
             if (F0CH) f0_issue(nch * kChunk);
@@ -501,14 +503,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             if (ABL(p, 2)) continue;
             float f[kChunk];
             {
-                const float4 *fq = reinterpret_cast<const float4 *>(f0s + (rd * 32 + cr) * CS + (F0CH ? 0 : c0));
+                const float4 *fq = reinterpret_cast<const float4 *>(f0s + f0_row(rd * 32 + cr) * CS + (F0CH ? 0 : c0));
                 const float4 a0 = fq[0], a1 = fq[1], a2 = fq[2], a3 = fq[3];
                 f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
                 f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w; f[12] = a3.x; f[13] = a3.y; f[14] = a3.z; f[15] = a3.w;
             }
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
-                const float4 *q = s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu));
+                const float4 *q = kApk ? s4 + ((t & 1) ? (apk[rd][t >> 1] >> 16) : (apk[rd][t >> 1] & 0xFFFFu))
+                                       : reinterpret_cast<const float4 *>(smem + apk[rd][t]);
                 const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
                 float a = acc[rd][t];
                 a = fmaf(f[0], v0.x, a);  a = fmaf(f[1], v0.y, a);  a = fmaf(f[2], v0.z, a);  a = fmaf(f[3], v0.w, a);
@@ -538,6 +541,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
 
     // ---- epilogue: D -> LDS, bilinear combination, coalesced stores ----------------------------------------------------
+    if (kTableLate) {
+        if (!ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+        if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    }
     __syncthreads();
     STAMP(10);
 #pragma unroll
@@ -546,7 +553,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
             const int pp = s16 + 16 * t;
-            if (pp < P && !ABL(p, 16)) dbuf[cell * DS + pp] = acc[rd][t];
+            if (pp < P && !ABL(p, 16)) dbuf[cell * DS + rd * kSkew + pp] = acc[rd][t];
         }
     }
     STAMP(11);
@@ -560,8 +567,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const int flag = cellFlag[cell];
         if ((gi < G) & (gj < G) & !(flag & kCellSlow) & !ABL(p, 8)) {
             const bool empty = (flag & kCellEmpty) != 0;
-            const float *dc = dbuf + cell * DS;
-            const float *tc = tab + cell * TS;
+            const float *dc = dbuf + cell * DS + (ec >> 3) * kSkew;
+            const float *tc = tab + cell * TS + (ec >> 3) * kSkew;
             const unsigned goff = (unsigned)(gi * G + gj) * 4u;
             const rsrc_t outr = make_rsrc(p.out + (size_t)b * p.out_bs, (unsigned)K * GG4);
             float wx1[D], wx0[D];
@@ -601,6 +608,9 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #endif
 
     // ---- flagged cells: general per-tap routine (about one cell in 10^4) ---------------------------------------------
+#ifdef GFN_LEAN_ANALYZE
+    return;
+#endif
     const int nslow = __builtin_amdgcn_readfirstlane(hdr[4]);
     if (nslow != 0) {  // block-uniform, rare
         __syncthreads();
@@ -629,8 +639,17 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 // Only where the register budget allows it (r >= 3: 128 VGPRs per lane; the r <= 2 kernels live on 80 for three workgroups per
 // CU and keep the separate second launch).  One worker per CU: with a handful of listed tiles all but a few leave at once,
 // under wild flow (every tile listed, the tile workgroups leaving at once) they have the chip like the separate launch had.
+// Round 5 A/B: with the worker inlined the r >= 3 kernels' metadata shows 72-79 VGPR spills, ~160 SGPR spills and
+// ~300 bytes of scratch -- all of it in the worker branch (the ISA of the four lean_tile variants has no scratch access and 20 SGPR
+// spills, exactly what the -DGFN_LEAN_INLINE_WORKERS=0 build shows for the whole kernel: 117-123 VGPRs, no spills, no scratch).
+// As a launch of its own behind the tile kernel the worker costs nothing when the list is empty (94.7 vs 95.1 us, r = 4, 64
+// directions) but 12 us of serial tail when three tiles are listed, which is the bench's situation (95.9 vs 108.5 us): the inlined
+// form stays the default.
+#ifndef GFN_LEAN_INLINE_WORKERS
+#define GFN_LEAN_INLINE_WORKERS 1
+#endif
 template <int R>
-constexpr int lean_workers() { return R >= 3 ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
+constexpr int lean_workers() { return (GFN_LEAN_INLINE_WORKERS && R >= 3) ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
 
 template <int R, int NCH, typename FT>
 __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
@@ -670,6 +689,10 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     }
     const int b = pg[1], row0 = pg[2] & 0xffff, col0 = pg[2] >> 16;
     const bool interior = (flags & kPlanInterior) != 0;
+#ifdef GFN_LEAN_ANALYZE  // tools/isa_phases.py: only the interior whole-tile variant, so that the hot path is straight-line code in the dump
+    lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+    return;
+#endif
     if (flags & kPlanHalves) {
         if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
         else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);

@@ -1,12 +1,12 @@
 // local_corr_mq.h -- round 3: large windows (r >= 5 on 64-channel maps: GFNet's r = 6 at stride 8 and r = 7 at stride 16) with the
-// D-stage on the matrix core.  Included by local_corr.hip after local_corr_mm.h: the split-bf16 formulation, the swizzled slots,
+// D-stage on the matrix core.  Included by local_corr.hip after local_corr_mstage.h: the split-bf16 formulation, the swizzled slots,
 // the staging helpers (mm_item / mm_issue / mm_commit) and the guarded D buffer are that file's; what differs is the shape of the
 // kernel around them.
 //
 // Why here and not at r = 3, 4: a cell at r = 6 / 7 takes 196 / 256 products per channel (r = 4: 100) and the round-1 kernel's
 // D-stage feeds every v_fma_f32 with an LDS dword of its own -- at these radii that stage is ~2 k cycles per 16-channel chunk and
 // wave, four chunks a tile.  On the matrix core the same chunk is <= 20 instructions of 16 cycles.  The persistent one-workgroup
-// kernel of local_corr_mm.h lost that gain again at these shapes (two passes, 40 accumulator registers beside two passes' loads:
+// kernel of round 3 (deleted in round 5, see local_corr_mstage.h) lost that gain again at these shapes (two passes, 40 accumulator registers beside two passes' loads:
 // spills; every phase in lockstep across the CU).  This kernel keeps the round-1 launch shape instead:
 //   * a tile is 2 x 16 cells = two groups of 2 x 8 (the N = 16 of v_mfma_f32_16x16x32_bf16), one 8-wave workgroup per tile, two
 //     workgroups per CU (80 KB of LDS each): one stages while the other multiplies;
@@ -22,7 +22,7 @@
 // The matrix core took the D-stage off the critical path; what is left is the latency of dependent loads with two workgroups per CU to
 // overlap it.  Tried without effect: the flows through the scalar cache (s_load_dwordx16 + v_writelane) and s_setprio for the set-up
 // wave (the wait is the memory round trip, not queueing or issue slots); skipping empty staging items by a branch.
-// Numerics: the class of local_corr_mm.h (products exact in fp32 up to 2^-17 relative per term, fp32 accumulation; fp16 maps split
+// Numerics: split-bf16 (local_corr_mstage.h; products exact in fp32 up to 2^-17 relative per term, fp32 accumulation; fp16 maps split
 // exactly), not bit-identical to the fp32 FMA kernels.  -DGFN_MQ=0 builds keep r >= 5 on the round-1 kernel.
 
 #ifndef GFN_MQ

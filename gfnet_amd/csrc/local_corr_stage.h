@@ -71,7 +71,7 @@ constexpr int kQuadPre = 2;  // work items of a chunk in flight per wave (region
 struct QuadItem {
     unsigned voff;        // byte offset of the lane's quad: (row * W + x) elements + the channel quad's four planes
     unsigned meta;        // bits 0-12: index of the lane's first pixel slot (+ cg) in units of 80 / UNIT bytes (UNIT 5: float4s, the
-                          // fp32 stage; UNIT 10: 8-byte pieces, the bf16 hi/lo stage of local_corr_mm.h); 13-16: pixels of the quad
+                          // fp32 stage; UNIT 10: 8-byte pieces, the bf16 hi/lo stage of local_corr_mstage.h); 13-16: pixels of the quad
                           // inside the image (CHECK); 17: the lane has a quad in this item; 18: its row lies inside the image (CHECK)
 };
 struct QuadLane {         // per lane and region, the first kQuadPre items of this wave

@@ -84,8 +84,7 @@ int gfn_local_corr_fwd(const float *f0, int64_t f0_bs, const float *f1, const fl
  * 64-channel maps the matrix-core tile kernel of csrc/local_corr_mq.h -- split-bf16 products with fp32 accumulation, NOT bit-identical to
  * the fp32 FMA kernels: each product is exact to 2^-17 relative, so a value is within 2^-17 * sum_c |f0_c * f1_c| / sqrt(C) of the fp32
  * result (a few 1e-6, i.e. inside 1e-4 * max(1, |ref|), on unit-scale features; the bound follows the operands' magnitude, not the
- * result's; variant 4 is the opt-out, gfnet_amd.ops.LOCAL_CORR_FP32 in Python) -- and the round-1 tile kernel above for other channel counts; builds with
- * -DGFN_MM_DEFAULT=1 also send r = 3, 4 to a matrix-core kernel, csrc/local_corr_mm.h), 1 = force the general per-tap kernel, 2 = the
+ * result's; variant 4 is the opt-out, gfnet_amd.ops.LOCAL_CORR_FP32 in Python) -- and the round-1 tile kernel above for other channel counts), 1 = force the general per-tap kernel, 2 = the
  * round-1 fp32 tile kernel for every radius (the cross-check of the other paths), 4 = fp32 FMA arithmetic whatever the radius: the lean
  * tile path for r <= 4, the round-1 kernel for r >= 5 (bit-identical to 2); + 8: the plan of this call is already in scratch
  * (gfn_refiner_input_plan_fwd_dt; only with 0).  Same arguments otherwise.

@@ -136,7 +136,9 @@ def test_product_kernels_keep_their_register_budget():
     """spills of the product kernels are tracked, not discovered.  From the metadata of the built objects
     (tools/kernel_regs.py): the fp32 instantiations of the default local-correlation paths stay spill-free where they are today
     (lean r <= 2, the r >= 5 matrix-core kernel), the known exceptions stay bounded -- the lean r = 3 / 4 kernels carry the
-    second-launch worker path (73 spilled registers, worker workgroups only).  The fp16 instantiations of the r >= 5 kernels (pyramids
+    second-launch worker path (<= 80 spilled registers, all in the worker branch: the -DGFN_LEAN_INLINE_WORKERS=0 build of the same
+    kernels has no spills and no scratch, csrc/local_corr_lean.h; round 5 measured the separate launch 12 us slower under the
+    bench's flows and kept the inlined form).  The fp16 instantiations of the r >= 5 kernels (pyramids
     stored in fp16, BASELINE configs[4]) spilled 16-39 registers until round 4: the choice between the two staging forms was a run-time
     flag for fp16 maps (even / odd width) and both forms' load registers were live at once; it is a template parameter now (QOK) and
     the even-width instantiations sit at 78-105 registers, the odd-width ones at <= 128 with at most one spill."""
@@ -150,10 +152,10 @@ def test_product_kernels_keep_their_register_budget():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_regs.py"), obj], capture_output=True, text=True, check=True).stdout
     seen = 0
     for line in out.splitlines():
-        m = re.search(r"(local_corr_\w+?)(?:I|<)(.*?)\s+vgpr\s+(\d+) spill\s+(\d+)", line)
+        m = re.search(r"(local_corr_\w+?)(?:I|<)(.*?)\s+vgpr\s+(\d+) spill\s+(\d+).*?scratch\s+(\d+)", line)
         if not m:
             continue
-        name, rest, vgpr, spill = m.group(1), line, int(m.group(3)), int(m.group(4))
+        name, rest, vgpr, spill, scratch = m.group(1), line, int(m.group(3)), int(m.group(4)), int(m.group(5))
         half = "DF16_" in rest or "_Float16" in rest
         if "tile2_kernel" in name:
             r = int(re.search(r"tile2_kernel(?:ILi|<)(\d)", rest).group(1))
@@ -161,7 +163,7 @@ def test_product_kernels_keep_their_register_budget():
             if r <= 2:
                 assert spill <= 1 and vgpr <= 80, line          # three workgroups per CU
             else:
-                assert spill <= 80 and vgpr <= 128, line        # the worker path's spills
+                assert spill <= 80 and scratch <= 330 and vgpr <= 128, line        # the worker branch's spills
         elif "mq_kernel" in name:
             seen += 1
             assert vgpr <= 128, line

@@ -111,8 +111,8 @@ def test_production_shapes_vs_oracle(c, hs, G, r, flow_kind):
 def test_lean_tile_kernel_is_bit_identical_to_round1_kernel(c, hs, G, r, flow_kind):
     """The round-2 lean tile kernel (variant 4, r <= 4) keeps the round-1 kernel's arithmetic (same D accumulation order, same
     epilogue): the two must agree bit for bit, whatever path a tile takes (staged, second launch, per-tap, empty windows).
-    Round 3: where the default path (variant 0) runs the D-stage on the matrix core (split-bf16 operands, csrc/local_corr_mm.h)
-    it is a different numerics class: within the tolerance of the fp32 FMA kernels and of the oracle, on every flow kind."""
+    Round 3: where the default path (variant 0) runs the D-stage on the matrix core (split-bf16 operands, r >= 5 on 64-channel maps:
+    csrc/local_corr_mq.h) it is a different numerics class: within the tolerance of the fp32 FMA kernels and of the oracle."""
     B = 4
     f0 = synth.lattice_normalish((B, c, G, G), 231 + r)
     f1 = synth.lattice_normalish((B, c, hs, hs), 232 + r)

@@ -1,7 +1,11 @@
-"""Timing (GPU): one half-map conv block per refiner width; GFN_CONV_TPB / GFN_CONV_NB1 in the environment select launch shapes."""
+"""Timing (GPU): one half-map conv block per refiner width; GFN_CONV_TPB / GFN_CONV_NB1 in the environment select launch shapes
+(read only by the -DGFN_ABLATE build, python -m gfnet_amd.build --ablate, which this tool loads when it exists)."""
 import os, sys
-import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_abl = os.path.join(ROOT, "gfnet_amd", "csrc", "libgfnet_hip_ablate.so")
+if os.path.exists(_abl) and "GFNET_HIP_LIB" not in os.environ:
+    os.environ["GFNET_HIP_LIB"] = _abl
+import torch
 sys.path.insert(0, ROOT)
 from gfnet_amd import ops
 B = 64
