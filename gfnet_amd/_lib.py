@@ -103,7 +103,8 @@ def check(code, what):
         msg = lib().gfn_last_error().decode()
         # gfn_local_corr_fwd wants its scratch counters zero on entry and only a call that ran to the end leaves them so
         # (include/gfnet_hip.h): after any failure the cached buffers are dropped, the next call gets freshly zeroed ones
-        _retired.extend(_scratch.values())  # (not freed: a captured graph may still name them)
+        for b in _scratch.values():
+            _retire(b)  # (not freed where a captured graph may still name them)
         _scratch.clear()
         raise GfnError(f"{what} failed ({code}): {msg}")
 
@@ -131,7 +132,21 @@ def require_gpu(*tensors):
 
 
 _scratch = {}
-_retired = []  # outgrown or dropped scratch buffers, kept alive for captured graphs that still name them
+_retired = []  # outgrown or dropped scratch buffers that were handed out DURING a stream capture: a hipGraph still names them
+_in_graphs = set()  # data_ptr of every buffer scratch() returned while its stream was capturing
+
+
+def _retire(buf):
+    """A buffer leaves the cache: kept alive only if a captured graph may name it (the list used to take every outgrown or
+    dropped buffer, ~9 MB each at 448b32, whether or not a graph had ever been captured)."""
+    if buf.data_ptr() in _in_graphs:
+        _retired.append(buf)
+
+
+def release_retired():
+    """Free the scratch buffers kept alive for captured graphs; call after destroying those graphs."""
+    _in_graphs.difference_update(b.data_ptr() for b in _retired)
+    _retired.clear()
 
 
 def scratch(device, nbytes):
@@ -145,10 +160,12 @@ def scratch(device, nbytes):
         # address (round 4: two scenes of different sizes captured on one stream -- the second capture grew the buffer and the first
         # graph's replays ended in a memory fault).  A few MB per growth step, a handful of steps per process.
         if buf is not None:
-            _retired.append(buf)
+            _retire(buf)
         # zero-filled: gfn_local_corr_fwd wants its counters zero on entry and leaves them zero (include/gfnet_hip.h)
         buf = torch.zeros((max(nbytes, 1 << 16) + 3) // 4, device=device, dtype=torch.int32)
         _scratch[key] = buf
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        _in_graphs.add(buf.data_ptr())
     return buf
 
 

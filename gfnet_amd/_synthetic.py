@@ -13,6 +13,14 @@ DISP = {"16": 64, "8": 64, "4": 32, "2": 16, "1": 8}
 RADIUS = [7, 6, 4, 2, 0]
 SCALES = ["16", "8", "4", "2", "1"]
 FLOW_NOISE_PX = 0.5    # true flow + N(0, (0.5/S)^2) in normalised units
+# Stress flows (bench.py --flows): what the refiner of a scale hands to the next one when it is NOT a near-perfect
+# matcher.  "noisy": the per-scale noise of the stand-in increment is several image pixels at the coarse scales (a scale's local
+# correlation sees the previous scale's output, bilinearly resized); "random": the scale-8 refiner returns flows uniform in
+# [-0.9, 0.9] (every window of the scale-4 call scattered: all of its tiles go through the second launch's gather path), the
+# later scales pull the flow back onto the truth.
+FLOW_MODES = {"true": {"16": 1, "8": 1, "4": 1, "2": 1, "1": 1},
+              "noisy": {"16": 8, "8": 8, "4": 4, "2": 2, "1": 1},      # x 0.5 px: 4 / 4 / 2 / 1 / 0.5 image pixels
+              "random": {"16": 1, "8": None, "4": 1, "2": 1, "1": 1}}
 
 WORKLOADS = {
     "448b32": {"sizes": [448], "pairs": 32, "num_itr": [1] * 5, "dtype": "fp32", "cpu_pairs": 2,
@@ -128,8 +136,11 @@ class StandInRefiner(nn.Module):
 class Scene:
     """Everything one image size needs: pyramids of both passes, true warps + noise on every grid, the model."""
 
-    def __init__(self, size, pairs, num_itr, dtype, conv_stack, dev, rank, upsample=True):
+    def __init__(self, size, pairs, num_itr, dtype, conv_stack, dev, rank, upsample=True, flows="true"):
         from gfnet_amd.model.network import GFNet
+
+        self.flows = flows
+        mult = FLOW_MODES[flows]
 
         self.size, self.up, self.B, self.num_itr = size, int(size * 1.25), pairs, num_itr
         gen_cpu = torch.Generator().manual_seed(1000 + rank + 7 * size)
@@ -154,7 +165,10 @@ class Scene:
             uses = [(self.grids[i], S0)] + ([(self.grids_up[i - 1], S1)] if upsample and i >= 1 else [])
             for G, S in uses:
                 k = 4.0 * S / int(s)  # undone by network.py:262-263's scale / (4 * W0)
-                targets[s][G] = ([(self.gt[G] + n.to(dev)) * k for n in self.noise[G][:num_itr[i]]], k)
+                if mult[s] is None:   # uniform flows (seeded): the next scale's windows land anywhere in the map
+                    targets[s][G] = ([(torch.rand(self.gt[G].shape, generator=gen_cpu).to(dev) * 1.8 - 0.9) * k for _ in range(num_itr[i])], k)
+                else:
+                    targets[s][G] = ([(self.gt[G] + n.to(dev) * float(mult[s])) * k for n in self.noise[G][:num_itr[i]]], k)
         refiners = nn.ModuleDict({s: StandInRefiner(FEAT[s], DISP[s], RADIUS[i], int(s), targets[s], num_itr[i], conv_stack)
                                   for i, s in enumerate(SCALES)})
         conf = {"encoder_cfg": {"feat_chs": [64, 32, 16, 8]},

@@ -258,9 +258,33 @@ class GFNet(nn.Module):
         self.symmetric = symmetric
         self.attenuate_cert = attenuate_cert
         self.h_resized, self.w_resized = initial_res
+        self.initial_res = initial_res
         self.exact_softmax = exact_softmax
         self.amp, self.amp_dtype = amp, amp_dtype
         self.ransac_iters = 2000  # OpenCV's default maxIters for findHomography
+
+    # ---- checkpoints ---------------------------------------------------------------------------------
+    REFERENCE_BACKBONE_PREFIXES = ("dino_decoder", "encoder", "decoder", "merge_layer")  # the reference's registered submodules
+                                                                                         # beside conv_refiner (network.py:47-60)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Accepts a FULL reference checkpoint (test.py:37-38: `model.load_state_dict(states["model"])`): `conv_refiner.*` entries load
+        as they are (same parameter names); an entry of the reference's backbone goes to `backbone.<name>` when the injected backbone
+        is a module that has it, and is set aside otherwise (`self.ignored_backbone_keys`; the backbone is host code outside this
+        package).  Anything else is reported by torch as usual."""
+        own = self.state_dict()
+        routed, ignored = {}, []
+        for k, v in state_dict.items():
+            if k in own:
+                routed[k] = v
+            elif "backbone." + k in own:
+                routed["backbone." + k] = v
+            elif k.split(".")[0] in self.REFERENCE_BACKBONE_PREFIXES:
+                ignored.append(k)
+            else:
+                routed[k] = v
+        self.ignored_backbone_keys = ignored
+        return super().load_state_dict(routed, strict=strict, assign=assign)
 
     # ---- the two methods GFNet.forward calls at scale 16 (network.py:251-252) -------------------
     def corr_volume(self, feat0, feat1):

@@ -30,6 +30,19 @@ def host(t):
                                                       (448, [1] * 5, torch.float32, 1), (448, [2] * 5, torch.float32, 1),
                                                       (224, [1, 2, 1, 1, 2], torch.float32, 4)])
 def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype, pairs):
+    _whole_path_vs_oracle(size, num_itr, dtype, pairs, range(pairs))
+
+
+def test_whole_path_at_the_metric_batch_vs_oracle():
+    """the batch the metric is quoted on -- Scene(448, 32 pairs) = 64 directions, exactly what bench.py steps --
+    through both passes and match_post, four pairs OF THAT BATCH (first, last and two seeded picks) against their own oracle walks:
+    batch indexing at B = 32 / 64 directions of every kernel of the loop, not only of the local correlation."""
+    rng = np.random.default_rng(5)
+    which = sorted({0, 31, *(int(v) for v in rng.choice(np.arange(1, 31), 2, replace=False))})
+    _whole_path_vs_oracle(448, [1] * 5, torch.float32, 32, which)
+
+
+def _whole_path_vs_oracle(size, num_itr, dtype, pairs, which):
     """672-, 448- and 224-sized pyramids (not 448 pyramids in a bigger image) through forward_pyramids of both passes with the
     refiner iterations of map.json / basic.json; every flow / certainty the loop produces against the oracle's, then match_post.
     448 is BASELINE configs[1]'s own loop (model/network.py:230-281, 326-349 at 448 / 560); the 4-pair case (8 directions)
@@ -67,7 +80,7 @@ def test_whole_path_per_scale_and_iteration_vs_oracle(size, num_itr, dtype, pair
         assert np.abs(got - ref)[amb].max(initial=0) < 8.0 / size, what  # a flipped cell is off by one displacement (~ the flow noise)
         return amb
 
-    for b in range(pairs):
+    for b in which:
         rows = [b, b + pairs]  # the pair's two directions in the symmetric batch
         r1, r2, warp_o, cert_o = cpu_pair(sc, b, npyr, nup, np_gt, np_noise, seed=0, return_all=True)
         last_amb = None

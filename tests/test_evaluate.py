@@ -72,8 +72,8 @@ def _gather_worker(rank, world, port, n, q):
 
     parallel.init_from_env(backend="gloo")
     lo, hi = parallel.shard_range(n, rank, world)
-    errs, t = evaluate._gather(np.arange(lo, hi, dtype=np.float64) * 0.5, 1.0 + rank, n, lo, world)
-    q.put((rank, errs, t))
+    errs, t, w = evaluate._gather(np.arange(lo, hi, dtype=np.float64) * 0.5, 1.0 + rank, 3.0 + rank, n, lo, world)
+    q.put((rank, errs, (t, w)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -93,7 +93,7 @@ def test_error_gather_world2_gloo():
         assert p.exitcode == 0
     for _, errs, t in res:
         np.testing.assert_array_equal(errs, np.arange(7) * 0.5)
-        assert t == pytest.approx(1.5)
+        assert t[0] == pytest.approx(1.5) and t[1] == pytest.approx(3.5)
 
 
 class _OracleMatcher:
@@ -141,6 +141,36 @@ def test_evaluate_recovers_known_homographies(tmp_path):
     assert res["ace"] == pytest.approx(float(np.mean(res["errors"])))
     assert all(res[f"auc@{t}"] > 0.99 for t in (3, 5, 10, 20))
     assert res["time"] > 0
+
+
+@pytest.mark.gpu
+def test_evaluate_time_is_device_time_under_a_slow_loader(tmp_path, monkeypatch):
+    """with a loader slower than the device work (real JPEG / PNG sets), `time` must still be the device seconds per pair --
+    every batch's [first upload, solved] interval on the HIP-event clock, merged -- not wall time minus decoding (which also took away
+    the device work that ran under the decoding of the next batch), and `wall_time` carries the decoding."""
+    import time as _time
+
+    from gfnet_amd import evaluate
+
+    sizes = [(96, 96)] * 6
+    Hs = _homographies(6, 64, corner=0.08)
+    _write_dataset(str(tmp_path), Hs, sizes)
+
+    class Busy(_OracleMatcher):  # ~20 ms of device work per batch that no host timer inside evaluate() sees
+        def match_batch(self, A, B):
+            torch.cuda._sleep(40_000_000)
+            return super().match_batch(A, B)
+
+    real = evaluate._load_image
+    monkeypatch.setattr(evaluate, "_load_image", lambda p: (_time.sleep(0.03), real(p))[1])  # 60 ms of "decoding" per pair
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); torch.cuda._sleep(40_000_000); ev1.record(); torch.cuda.synchronize()
+    sleep_s = ev0.elapsed_time(ev1) * 1e-3
+    res = evaluate.evaluate(Busy(Hs), str(tmp_path), batch_size=2, num_samples=2000)
+    per_pair_device = 3 * sleep_s / 6                     # three batches, each at least one sleep kernel long
+    assert res["time"] >= 0.9 * per_pair_device, (res["time"], per_pair_device)
+    assert res["wall_time"] >= 0.06 and res["wall_time"] >= res["time"]
+    assert res["time"] < res["wall_time"]                 # decoding is in wall_time only
 
 
 class _TwoCallMatcher(_OracleMatcher):

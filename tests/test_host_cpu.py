@@ -174,3 +174,59 @@ def test_product_kernels_keep_their_register_budget():
                 seen += 1
                 assert vgpr <= 128 and spill == 0, line  # two workgroups of eight waves per CU
     assert seen >= 12
+
+
+def test_compat_directory_resolves_the_reference_imports():
+    """with compat/ in front on sys.path the reference's own import lines (test.py:9-11, model/network.py:10-11)
+    bind to gfnet_amd -- in a child process, so that this process's `utils` / `model` modules are not disturbed."""
+    import subprocess
+    import sys
+
+    code = ("from model.network import GFNet; from estimation import demo_estimation, auc; "
+            "from utils.local_correlation import local_correlation; from utils.kde import kde; "
+            "import gfnet_amd.model.network as n, gfnet_amd.estimation as e, gfnet_amd.utils.local_correlation as l, gfnet_amd.utils.kde as k; "
+            "assert GFNet is n.GFNet and demo_estimation is e.demo_estimation and auc is e.auc; "
+            "assert local_correlation is l.local_correlation and kde is k.kde; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+def test_gfnet_loads_a_full_reference_checkpoint():
+    """test.py:37-38 hands load_state_dict the whole `states["model"]`: conv_refiner.* entries load, the reference's backbone entries
+    (dino_decoder / encoder / decoder / merge_layer, network.py:47-60) are set aside without a backbone module and routed into one
+    that has them; an unknown key is still an error under strict=True."""
+    import torch.nn as nn
+
+    from gfnet_amd.model.network import GFNet
+
+    conf = {"encoder_cfg": {"feat_chs": [64, 32, 16, 8]},
+            "matcher": {"num_grid": [32, 32, 64, 128, 256], "radius": [7, 6, 4, 2, 0],
+                        "displacement_dim": [64, 64, 32, 16, 8], "num_itr": [1, 1, 1, 1, 1]}}
+    torch.manual_seed(3)
+    src = GFNet(conf)
+    ckpt = {k: v + 1.0 if v.is_floating_point() else v for k, v in src.state_dict().items()}
+    ckpt.update({"encoder.layer0.weight": torch.ones(4, 4), "decoder.up.bias": torch.zeros(4), "dino_decoder.blocks.0.w": torch.zeros(2),
+                 "merge_layer.0.weight": torch.full((3,), 2.0)})
+    dst = GFNet(conf, initial_res=(448, 448), upsample_res=(560, 560), symmetric=True, upsample_preds=True, attenuate_cert=True)
+    assert dst.initial_res == (448, 448)
+    res = dst.load_state_dict(ckpt)  # strict
+    assert not res.missing_keys and not res.unexpected_keys
+    assert sorted(dst.ignored_backbone_keys) == ["decoder.up.bias", "dino_decoder.blocks.0.w", "encoder.layer0.weight", "merge_layer.0.weight"]
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, ckpt[k]), k
+
+    class Backbone(nn.Module):  # a wrapper with (some of) the reference's submodule names
+        def __init__(self):
+            super().__init__()
+            self.merge_layer = nn.Sequential(nn.BatchNorm1d(3))
+
+        def forward(self, x, upsample=False):
+            raise NotImplementedError
+
+    dst2 = GFNet(conf, backbone=Backbone())
+    dst2.load_state_dict(ckpt, strict=False)
+    assert torch.equal(dst2.backbone.merge_layer[0].weight, torch.full((3,), 2.0))
+    assert "merge_layer.0.weight" not in dst2.ignored_backbone_keys
+    with pytest.raises(RuntimeError):
+        dst.load_state_dict(dict(ckpt, bogus=torch.zeros(1)))
