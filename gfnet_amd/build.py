@@ -41,10 +41,7 @@ def _stale(out, deps):
 
 
 # per-file flags.  kde.hip: MFMA results straight into VGPRs -- every one of them feeds a v_exp_f32, which cannot read AGPRs
-# local_corr.hip (round 5): the fp32 matrix-core D-stage of the lean r = 4 kernel keeps 13 accumulator quads beside the staging registers under a
-# 128-register budget; with the AGPR form the compiler halves that budget between the two files and spills (909 -> 281 spill instructions;
-# the r >= 5 bf16 kernels of the same file allocate exactly as before)
-FILE_FLAGS = {"kde.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "local_corr.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FILE_FLAGS = {"kde.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _compile(src, verbose, extra):

@@ -33,8 +33,6 @@
 //
 // Block->tile mapping is XCD-aware (common.h): consecutive tiles of one image stay on one XCD so
 // the 3-4x halo re-reads of f1 are served by that XCD's L2, not HBM.
-#include <type_traits>
-
 #include "common.h"
 #include "refiner_input.h"
 
@@ -73,7 +71,6 @@ struct LcParams {
     long todo_ints;
     int planned;                      // lean path: the plan is already in scratch (gfn_refiner_input_plan_fwd_dt wrote it)
     int mq;                           // r >= 5: the first launch is the matrix-core tile kernel (local_corr_mq.h)
-    int mx;                           // lean path, Lean<R>::kMx: the plan is for / the tiles go to the fp32 matrix-core D-stage (round 5)
     int *plan;                        // lean path: [4 * B*tiles] per-tile staging regions written by the plan launch (16-byte aligned)
 #ifdef GFN_ABLATE
     int dbg;  // timing experiments only (tools/probe_local_corr.py): bit mask of stages to skip
@@ -891,11 +888,6 @@ bool lean_shape(int C, int H, int W, int G, int r, int f16) {
     return true;
 }
 
-// shapes whose lean tile kernel runs its D-stage on the fp32 matrix-core instruction (Lean<R>::kMx; exact, same bits)
-bool mx_shape(int C, int H, int W, int G, int r, int f16) {
-    return GFN_LEAN_MX != 0 && r == 4 && lean_shape(C, H, W, G, r, f16);
-}
-
 // large windows on 64-channel maps: the matrix-core tile kernel of local_corr_mq.h is the first launch (byte offsets into the maps and
 // the kOffRange marker share 31 bits)
 bool mq_shape(int C, int H, int W, int G, int r, int f16) {
@@ -938,15 +930,8 @@ int device_cu_count() {
 
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, unsigned flags) {
-    (void)flags;
-    if constexpr (Lean<R>::kMx) {
-        if (p.mx) {   // the D-stage on v_mfma_f32_16x16x4_f32 (same results bit for bit; the plan was written for its stage layout)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-            hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT, true>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
-            return;
-        }
-    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)flags;
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
 
@@ -1129,7 +1114,6 @@ GFN_EXPORT int gfn_local_corr_fwd_dt(const float *f0, int64_t f0_bs, const void 
     if (variant == 4) variant = 0;
     const bool tiled = variant == 0 && flow && !grid_based && win_h == H && win_w == W;
     p.mq = (want_mm && tiled && mq_shape(C, H, W, G, r, p.f16)) ? 1 : 0;
-    p.mx = (want_mm && tiled && mx_shape(C, H, W, G, r, p.f16)) ? 1 : 0;   // variant 4: the fp32 FMA D-stage (the cross-check)
     bool lean = tiled && lean_shape(C, H, W, G, r, p.f16);
     if (planned && !lean) return gfn::fail(GFN_ERR_INVALID_ARG, "local_corr: variant 8 (plan present) on a call the lean path does not take");
     p.planned = planned ? 1 : 0;
@@ -1222,7 +1206,6 @@ GFN_EXPORT int gfn_refiner_input_plan_fwd_dt(const void *f0, const void *f1, int
     p.B = B; p.C = C; p.G = G; p.H = Hs; p.W = Ws;
     p.todo = reinterpret_cast<int *>(scratch);
     p.plan = lean_plan_ptr(scratch, B, G);
-    p.mx = mx_shape(C, Hs, Ws, G, r, dtype == GFN_F16) ? 1 : 0;  // the plan is for the default path of the call that follows (variant 0 + 8)
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == GFN_F16;
     switch (r) {

@@ -28,9 +28,6 @@ constexpr int kMmNBW = 10;  // local_corr_mq.h: accumulator blocks per wave of t
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
-#ifndef GFN_LEAN_MX
-#define GFN_LEAN_MX 0
-#endif
 constexpr int kPlanInts = 16;  // per tile: region A x0, y0, (h << 16) | w, flags; region B x0, y0, (h << 16) | w, geometry of A;
                                // geometry of B, direction b, row0 | col0 << 16, spare ...  (geometry = pitch | quads per row << 8 | items << 16:
                                // round 4 -- the tile kernel no longer derives the regions' pitch and item count (region_fits) and the tile's
@@ -58,12 +55,6 @@ struct Lean {
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
-    // Round 5: the D-stage of this radius on v_mfma_f32_16x16x4_f32 (exact fp32: bit for bit the fmaf chain over the channels,
-    // tools/micro/mfma16x16x4.hip).  A group = 4 x 4 cells (the M = 16), a block = 4 x 4 pixels of the staged region (the N = 16), the
-    // K = 4 of an instruction = four channels; the stage holds [channel quad kk][pixel] units of 16 bytes (no padding: 1024 pixels).
-    static constexpr bool kMx = GFN_LEAN_MX != 0 && R == 4;
-    static constexpr int kMxCap = kStage / 64;   // pixels of a 16-channel chunk the stage holds in the matrix-core layout
-    static constexpr int kMxBox = 20;            // a group's windows span at most kMxBox x kMxBox pixels (5 x 5 blocks: 13 accumulator quads per wave)
 };
 
 // what one cell asks of the stage: patch origin, flags, unclipped window (if it touches the image)
@@ -111,18 +102,6 @@ __device__ __forceinline__ bool region_fits(RowPlan &u) {
     if ((long)u.pitch * u.h > Lean<R>::kCap || u.w > 64) return false;
     // a multiple of 8 items, so that they split evenly over the 8 waves (every wave issues the same number of loads: no
     // branches around loads, exact wait counts)
-    u.nitems = ((u.h * u.nq + 15) / 16 + 7) & ~7;
-    return true;
-}
-
-// the matrix-core layout (Lean<R>::kMx): row pitch == 4 (mod 8) pixels makes the 16-byte unit reads of a 4 x 4-pixel block conflict-free
-// in the hardware's b128 lane groups (rows 0 / 3 of channel quad kk and rows 1 / 2 of kk + 1 land on the four quarters of the banks)
-template <int R>
-__device__ __forceinline__ bool region_fits_mx(RowPlan &u) {
-    u.nq = (u.w + 3) >> 2;
-    u.pitch = (u.nq & 1) ? u.nq * 4 : u.nq * 4 + 4;
-    u.pu = (u.pitch * u.h + 15) & ~15;
-    if (u.pu > Lean<R>::kMxCap || u.nq > 15) return false;
     u.nitems = ((u.h * u.nq + 15) / 16 + 7) & ~7;
     return true;
 }
@@ -182,27 +161,6 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
             hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
         }
         const bool all_in = __all(c.inside);
-        bool mx_ok = true;
-        if (Lean<R>::kMx && p.mx) {
-            // boxes of the four 4 x 4-cell groups (tile columns 4 g .. 4 g + 3): a quad of lanes = four neighbouring cells of a tile row,
-            // quads 0 / 2 and 1 / 3 of a DPP row = two tile rows of one group, the two DPP rows of a half = its four tile rows
-            auto gmin = [](int v) {
-                v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-                v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-                v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));  // row_ror:8
-                return v;
-            };
-            const int qx0 = gmin(c.bx0), qy0 = gmin(c.by0), qx1 = gmin(-c.bx1), qy1 = gmin(-c.by1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int la = (g >> 1) * 32 + (g & 1) * 4, lb = la + 16;
-                const int gx0 = min(__builtin_amdgcn_readlane(qx0, la), __builtin_amdgcn_readlane(qx0, lb));
-                const int gy0 = min(__builtin_amdgcn_readlane(qy0, la), __builtin_amdgcn_readlane(qy0, lb));
-                const int gx1 = -min(__builtin_amdgcn_readlane(qx1, la), __builtin_amdgcn_readlane(qx1, lb));
-                const int gy1 = -min(__builtin_amdgcn_readlane(qy1, la), __builtin_amdgcn_readlane(qy1, lb));
-                if (gx0 != kFar) mx_ok &= (gx1 - gx0 <= Lean<R>::kMxBox) & (gy1 - gy0 <= Lean<R>::kMxBox);
-            }
-        }
         if (lane == 0) {
             auto region = [&](int bx0, int by0, int bx1, int by1, RowPlan &u) {
                 // Border tiles: the region starts on a multiple of 4 pixels, so that a quad never straddles the image's left
@@ -221,11 +179,10 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 u.w = max(bx1 - u.x0, 0);
                 u.h = max(by1 - by0, 0);
                 if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
-                if (Lean<R>::kMx && p.mx) return region_fits_mx<R>(u);
                 return region_fits<R>(u);
             };
             RowPlan ua, ub;
-            const bool border_ok = mx_ok;  // (matrix-core D-stage: a group whose windows span more than kMxBox pixels sends the tile to the second launch)
+            const bool border_ok = true;
             int flags = all_in ? kPlanInterior : 0;
             const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
             ub = ua;
@@ -301,21 +258,15 @@ struct DivPW {
 // falls back to vmcnt(0) and the cell set-up ends up waiting for the stage loads issued after it.
 // HALVES: the tile is staged as two 4 x 8-cell halves, one after the other (region uA for cells 0-31 = round 0, uB for cells
 // 32-63 = round 1); otherwise uA serves both rounds.
-typedef float mx_f32x4 __attribute__((ext_vector_type(4)));
-
-template <int R, int NCH, bool CHECK, bool HALVES, typename FT, bool MX = false>
+template <int R, int NCH, bool CHECK, bool HALVES, typename FT>
 __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, int b, int row0, int col0,
                                           int tid, int lane, int wave) {
-    constexpr int UNIT = MX ? kUnitMx : kSlotV4;  // staging layout (local_corr_stage.h)
     constexpr int ROUNDS = 2;
     constexpr int C = 16 * NCH;
     constexpr int kStageBytes = Lean<R>::kStage;  // shadows the round-1 constant
     constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
     constexpr int D = 2 * R + 1, K = D * D;
-    // D buffer: per cell PW rows of DROW floats (+ 1: odd cell stride, the epilogue's lanes are cells).  Matrix-core D-stage: rows of 16,
-    // a window's columns start at its offset from the block grid (0..3), so that the four columns of a block are filed under ONE test
-    constexpr int DROW = MX ? 16 : 2 * R + 2;
-    constexpr int NC = 64, DS = (2 * R + 2) * DROW + 1, TS = 2 * D + 1;
+    constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
     // Round 5: the epilogue's lanes 0-31 hold cells c and c + 32 (lane -> cell so that a wave stores whole grid-row segments), whose D
     // and table rows start 32 DS / 32 TS dwords apart = on the same bank: every epilogue read was a 2-way conflict.  Rows of cells
     // 32-63 are skewed by 16 dwords.
@@ -390,10 +341,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (f0_lane) {
 #pragma unroll
             for (int l = 0; l < NF0L; ++l) {
-                int ch = wave * NF0 + 4 * l + fk;   // channel inside what f0s holds
-                // matrix-core D-stage: channel c of a 16-channel chunk sits at 4 (c % 4) + c / 4, so that the float4 at 4 kk holds
-                // channels kk, 4 + kk, 8 + kk, 12 + kk -- the four k-steps of a lane with k index kk
-                if (MX) ch = (ch & ~15) | ((ch & 3) << 2) | ((ch >> 2) & 3);
+                const int ch = wave * NF0 + 4 * l + fk;   // channel inside what f0s holds
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int fc = 4 * fqd + e;
@@ -412,13 +360,13 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     auto quad_lane = [&](const RowPlan &u) {
         QuadLane ql;
 #pragma unroll
-        for (int n = 0; n < PRE; ++n) ql.it[n] = quad_item<CHECK, FT, UNIT, (R >= 3)>(u, H, W, wave, lane, n);
+        for (int n = 0; n < PRE; ++n) ql.it[n] = quad_item<CHECK, FT, kSlotV4, (R >= 3)>(u, H, W, wave, lane, n);
         return ql;
     };
     const QuadLane qlA = quad_lane(uA);
     const rsrc_t f1r = make_rsrc(f1_of<FT>(p, b), (unsigned)C * (unsigned)(H * W) * (unsigned)sizeof(FT));
     QuadRegs<PRE, FT> pre;
-    if (!ABL(p, 1)) quad_issue<PRE, CHECK, FT, UNIT, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
+    if (!ABL(p, 1)) quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, 0u, H, W, uA, wave, lane, qlA, 0);
     STAMP(1);
     const QuadLane qlB = HALVES ? quad_lane(uB) : qlA;
 
@@ -501,8 +449,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
     STAMP(2);
     if (!ABL(p, 1)) {
-        quad_commit<PRE, CHECK, FT, UNIT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
-        quad_rest<CHECK, FT, UNIT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
+        quad_commit<PRE, CHECK, FT>(s4, pre, H, W, uA, wave, lane, qlA, 0);
+        quad_rest<CHECK, FT>(s4, f1r, 0u, H, W, uA, wave, lane, qlA, PRE);
     }
     STAMP(3);
     __syncthreads();
@@ -518,7 +466,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
     }
 
-    if (!kFlowAll && !MX) {
+    if (!kFlowAll) {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) addressing(rd, cellX0[rd * 32 + cr], cellY0[rd * 32 + cr]);
     }
@@ -527,40 +475,6 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
         for (int t = 0; t < NP; ++t) acc[rd][t] = 0.f;
-    // ---- matrix-core D-stage (MX): wave = (group of 4 x 4 cells, parity of the block index) ---------------------------------------------
-    // D[cell][pixel] += sum_k f0[cell][4 m + k] * f1[4 m + k][pixel] per block of 4 x 4 pixels and k-step m: A = the group's f0 (lane
-    // (i, kk): cell i, channel 4 m + kk), B = one 16-byte unit per lane (pixel j = lane & 15 of the block, channel quad kk = lane >> 4),
-    // result register v of lane (j, kk) = D[cell 4 kk + v][pixel j].  Blocks s = 5 tr + tc of the group's box; this wave owns s of its
-    // parity, accumulators live across the chunks.
-    constexpr int kMxT = 5, kMxAcc = (kMxT * kMxT + 1) / 2;
-    mx_f32x4 macc[MX ? kMxAcc : 1];
-    const int mg = wave >> 1, mpar = wave & 1, mj = lane & 15, mkk = lane >> 4;
-    auto mx_cell = [&](int i) { const int col = 4 * mg + (i & 3); return ((col >> 3) << 5) | ((i >> 2) << 3) | (col & 7); };
-    int mgx0 = 0, mgy0 = 0, mntr = 0, mntc = 0;
-    unsigned mb_addr = 0, ma_addr = 0;
-    if (MX) {
-#pragma unroll
-        for (int t = 0; t < kMxAcc; ++t) macc[t] = mx_f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ci = mx_cell(mj);
-        const int cx = cellX0[ci], cy = cellY0[ci];
-        const bool has = cx != kFar;
-        const int x0 = row_min_i32(has ? cx : kFar), y0 = row_min_i32(has ? cy : kFar);
-        const int x1 = row_min_i32(has ? -(cx + PW) : kFar), y1 = row_min_i32(has ? -(cy + PW) : kFar);
-        mgx0 = __builtin_amdgcn_readlane(x0, 15);
-        mgy0 = __builtin_amdgcn_readlane(y0, 15);
-        const int gx1 = -__builtin_amdgcn_readlane(x1, 15), gy1 = -__builtin_amdgcn_readlane(y1, 15);
-        if (mgx0 != kFar) {   // (the plan keeps every box within kMxBox: 5 x 5 blocks)
-            mntc = min((gx1 - mgx0 + 3) >> 2, kMxT);
-            mntr = min((gy1 - mgy0 + 3) >> 2, kMxT);
-        } else {
-            mgx0 = 0; mgy0 = 0;
-        }
-        if (mpar == 0 && lane == 0) hdr[mg] = mgx0;   // the epilogue (lane = any cell of the tile) needs its group's box origin: read behind barriers
-        const RowPlan &u = (HALVES && mg >= 2) ? uB : uA;
-        // byte address of the lane's unit of block (0, 0): plane kk, pixel (row j / 4, column j % 4) of the box
-        mb_addr = (unsigned)(mkk * u.pu + (mgy0 - u.y0 + (mj >> 2)) * u.pitch + (mgx0 - u.x0) + (mj & 3)) * 16u;
-        ma_addr = (unsigned)(f0_row(ci) * CS + 4 * mkk) * 4u;
-    }
     STAMP(5);
 
     // ---- main loop: 16 channels at a time (per half when the tile is staged in halves) ------------------------------------
@@ -580,47 +494,11 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #pragma unroll
             for (int h = 0; h < (kApk ? (NP + 1) / 2 : NP); ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the (packed) addresses as they are: no recomputation per chunk
         if (more && !ABL(p, 1)) {  // next step's loads: in flight across this D-stage
-            quad_issue<PRE, CHECK, FT, UNIT, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
+            quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
             if (F0CH) f0_issue(nch * kChunk);
-        }
-        if (MX && !ABL(p, 2) && !(HALVES && (mg >> 1) != half) && mntr > 0) {   // scalar
-            const RowPlan &u = (HALVES && mg >= 2) ? uB : uA;
-            const mx_f32x4 a = *reinterpret_cast<const mx_f32x4 *>(reinterpret_cast<const unsigned char *>(f0s) + ma_addr + (unsigned)(F0CH ? 0 : c0) * 4u);
-            const unsigned rowstep = (unsigned)u.pitch * 64u;  // four region rows, in bytes
-            // The parity of a wave's blocks is a compile-time constant of the code it runs (one branch here, two copies of the block
-            // list): with a run-time parity test per block hipcc kept 25 condition masks alive across the chunks and spilled them.
-            // Blocks with tr, tc <= 2 exist in every box (a window is 10 pixels: at least 3 blocks each way) and are unconditional.
-            auto products = [&](auto par) {
-                constexpr int PAR = decltype(par)::value;
-#pragma unroll
-                for (int tr = 0; tr < kMxT; ++tr) {
-                    if (tr >= 3 && tr >= mntr) continue;   // scalar
-                    const unsigned char *brow = smem + mb_addr + (unsigned)tr * rowstep;
-                    // the row's blocks of this parity: operands first, then the four k-steps across the blocks (independent chains)
-                    const int first = ((tr * kMxT) & 1) ? (PAR ? 0 : 1) : (PAR ? 1 : 0);   // first column of this parity in the row (folds after unrolling)
-                    mx_f32x4 px[3];
-#pragma unroll
-                    for (int n = 0; n < 3; ++n) {
-                        const int tc = first + 2 * n;
-                        if (tc < kMxT && !(tc >= 3 && tc >= mntc)) px[n] = *reinterpret_cast<const mx_f32x4 *>(brow + tc * 64);
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                        for (int n = 0; n < 3; ++n) {
-                            const int tc = first + 2 * n;
-                            if (tc < kMxT && !(tc >= 3 && tc >= mntc))   // scalar
-                                macc[(tr * kMxT + tc) >> 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[n][m], a[m], macc[(tr * kMxT + tc) >> 1], 0, 0, 0);
-                        }
-                    }
-                }
-            };
-            if (mpar == 0) products(std::integral_constant<int, 0>{});
-            else products(std::integral_constant<int, 1>{});
         }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (MX) continue;
             if (HALVES && rd != half) continue;
             if (ABL(p, 2)) continue;
             float f[kChunk];
@@ -653,8 +531,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
             __syncthreads();  // everyone is done reading this step's pixels
             STAMP(7);
             if (!ABL(p, 1)) {
-                quad_commit<PRE, CHECK, FT, UNIT>(s4, pre, H, W, un, wave, lane, qn, 0);
-                quad_rest<CHECK, FT, UNIT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
+                quad_commit<PRE, CHECK, FT>(s4, pre, H, W, un, wave, lane, qn, 0);
+                quad_rest<CHECK, FT>(s4, f1r, next_off, H, W, un, wave, lane, qn, PRE);
             }
             if (F0CH) f0_commit();
             __syncthreads();
@@ -669,51 +547,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
     __syncthreads();
     STAMP(10);
-    if (MX && mntr > 0) {   // scalar
-        // accumulators -> D buffer.  The products are (pixels) x (cells): register v of lane (cell c = lane & 15 of the group, kk) is
-        // D[pixel (row kk, column v) of block (tr, tc)][c] -- a lane files for ONE cell, its four registers are four neighbouring columns
-        // of one window row.  D rows are 16 floats with the window starting at column dx & 3, so a block is inside the window's 16
-        // columns or outside as a whole: one test per block (window row inside AND block column in [dx >> 2, dx >> 2 + 3]) from a
-        // 25-bit mask built with one multiply (the valid rows / columns are runs), v_bfe_i32 + v_bfi_b32 per block; blocks outside
-        // are filed in a per-lane dump of the (now idle) upper part of the stage instead of branching.
-        const int cv = mx_cell(mj);
-        const int cx = cellX0[cv], cy = cellY0[cv];
-        const int dx = cx - mgx0, ry = mkk - (cy - mgy0);      // ry: window row of this lane's pixel row in block row 0 (<= 3)
-        const int ylo = max((3 - ry) >> 2, 0), yhi = min((PW - 1 - ry) >> 2, kMxT - 1);
-        const int xlo = dx >> 2, xhi = min(xlo + 3, kMxT - 1);
-        const unsigned yrun = 0x108421u & (((1u << (5 * (yhi - ylo + 1))) - 1u) << (5 * ylo));
-        const unsigned xrun = ((1u << (xhi - xlo + 1)) - 1u) << xlo;
-        unsigned inv = ~(xrun * yrun);   // bit 5 tr + tc CLEAR: block (tr, tc)'s row kk lies inside this cell's 16-column window rows
-        if (cx == kFar || ylo > yhi) inv = ~0u;
-        const unsigned dump = (unsigned)(kStageBytes * 3 / 4) + (unsigned)lane * 16u;   // + a block's offset (< 1.4 KB): inside the stage, past the D buffer
-        const unsigned dvb = (unsigned)((cv * DS + (cv >> 5) * kSkew + ry * DROW - 4 * xlo) * 4);
-        static_assert((NC * DS + kSkew) * 4 <= kStageBytes * 3 / 4, "the dump lies behind the D buffer");
-        auto filing = [&](auto par) {
-            constexpr int PAR = decltype(par)::value;
-#pragma unroll
-            for (int tr = 0; tr < kMxT; ++tr) {
-                if (tr >= 3 && tr >= mntr) continue;   // scalar
-#pragma unroll
-                for (int tc = 0; tc < kMxT; ++tc) {
-                    const int sblk = tr * kMxT + tc;
-                    if ((sblk & 1) != PAR) continue;
-                    if (tc >= 3 && tc >= mntc) continue;   // scalar
-                    const unsigned t = (unsigned)__builtin_amdgcn_sbfe((int)inv, sblk, 1);   // 0 inside, ~0 outside
-                    const unsigned addr = ((t & dump) | (~t & dvb)) + (unsigned)((tr * 4 * DROW + tc * 4) * 4);   // (32-bit wrap: dvb may be "negative")
-                    float *q = reinterpret_cast<float *>(smem + addr);
-                    if (!ABL(p, 16)) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) q[v] = macc[sblk >> 1][v];
-                    }
-                }
-            }
-        };
-        if (mpar == 0) filing(std::integral_constant<int, 0>{});
-        else filing(std::integral_constant<int, 1>{});
-    }
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
-        if (MX) continue;
         const int cell = rd * 32 + cr;
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
@@ -732,13 +567,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const int flag = cellFlag[cell];
         if ((gi < G) & (gj < G) & !(flag & kCellSlow) & !ABL(p, 8)) {
             const bool empty = (flag & kCellEmpty) != 0;
-            // (matrix-core D-stage: rows of 16 floats, the window starts at column (X0 - group box) & 3 = what the filing snapped off)
-            int dcol = 0;
-            if (MX) {
-                const int egx0 = hdr[ec >> 2];
-                dcol = (cellX0[cell] - egx0) & 3;
-            }
-            const float *dc = dbuf + cell * DS + (ec >> 3) * kSkew + dcol;
+            const float *dc = dbuf + cell * DS + (ec >> 3) * kSkew;
             const float *tc = tab + cell * TS + (ec >> 3) * kSkew;
             const unsigned goff = (unsigned)(gi * G + gj) * 4u;
             const rsrc_t outr = make_rsrc(p.out + (size_t)b * p.out_bs, (unsigned)K * GG4);
@@ -754,10 +583,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
                     // weights), every tap is then two instructions
                     const float wy1 = tc[D + ky];
                     const float wy1s = wy1 * p.inv_sqrt_c, wy0s = (1.f - wy1) * p.inv_sqrt_c;
-                    const float *d = dc + ky * DROW;
+                    const float *d = dc + ky * PW;
                     float m[PW];
 #pragma unroll
-                    for (int x = 0; x < PW; ++x) m[x] = fmaf(d[DROW + x], wy1s, d[x] * wy0s);
+                    for (int x = 0; x < PW; ++x) m[x] = fmaf(d[PW + x], wy1s, d[x] * wy0s);
 #pragma unroll
                     for (int kx = 0; kx < D; ++kx) {
                         const float val = fmaf(m[kx + 1], wx1[kx], m[kx] * wx0[kx]);
@@ -822,7 +651,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 template <int R>
 constexpr int lean_workers() { return (GFN_LEAN_INLINE_WORKERS && R >= 3) ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
 
-template <int R, int NCH, typename FT, bool MX = false>
+template <int R, int NCH, typename FT>
 __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kLeanWorkers = lean_workers<R>();
@@ -853,7 +682,6 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     // pitch, quads per row and items as the plan launch worked them out (region_fits, checked there)
     uA.pitch = pl[7] & 0xff; uA.nq = (pl[7] >> 8) & 0xff; uA.nitems = pl[7] >> 16;
     uB.pitch = pg[0] & 0xff; uB.nq = (pg[0] >> 8) & 0xff; uB.nitems = pg[0] >> 16;
-    uA.pu = (uA.pitch * uA.h + 15) & ~15; uB.pu = (uB.pitch * uB.h + 15) & ~15;   // (matrix-core layout only)
     if (ABL(p, 64)) {  // timing experiment: what a row ring would stage per tile
         uA.h = min(uA.h, 7); uB.h = min(uB.h, 7);
         (void)region_fits<R>(uA);
@@ -862,14 +690,14 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     const int b = pg[1], row0 = pg[2] & 0xffff, col0 = pg[2] >> 16;
     const bool interior = (flags & kPlanInterior) != 0;
 #ifdef GFN_LEAN_ANALYZE  // tools/isa_phases.py: only the interior whole-tile variant, so that the hot path is straight-line code in the dump
-    lean_tile<R, NCH, false, false, FT, MX>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+    lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     return;
 #endif
     if (flags & kPlanHalves) {
-        if (interior) lean_tile<R, NCH, false, true, FT, MX>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
-        else lean_tile<R, NCH, true, true, FT, MX>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     } else {
-        if (interior) lean_tile<R, NCH, false, false, FT, MX>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
-        else lean_tile<R, NCH, true, false, FT, MX>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        if (interior) lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
+        else lean_tile<R, NCH, true, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     }
 }

@@ -8,12 +8,7 @@ struct RowPlan {  // block-uniform (scalars)
     int nq;       // 16-byte quads per region row
     int nitems;   // work items of a 16-channel chunk (16 consecutive quads of the region, row major, x 4 channel quads): a
                   // multiple of 8, nitems / 8 per wave
-    int pu;       // UNIT == 0 (the fp32 matrix-core layout of local_corr_lean.h, round 5): 16-byte units per channel-quad plane
 };
-// UNIT == 0 selects the layout of the fp32 matrix-core D-stage: the stage is four planes [kk][pixel] of 16-byte units, unit (kk, pixel)
-// = channels kk, 4 + kk, 8 + kk, 12 + kk of the chunk (a lane of v_mfma_f32_16x16x4_f32 with k index kk reads ONE unit per pixel and
-// feeds four k-steps from it, in channel order); a staging lane's channel quad cg takes those four planes, 4 planes apart.
-constexpr int kUnitMx = 0;
 
 // ---- buffer addressing --------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -107,9 +102,8 @@ __device__ __forceinline__ QuadItem quad_item(const RowPlan &u, int H, int W, in
     // idle lanes ask for an offset past the descriptor's range: the buffer load returns zeros without a memory access (a repeated
     // valid address cost a full trip through the texture-address path, which is what the tile kernels queue for)
     // (OOR: the r >= 3 kernels; the r <= 2 kernels live on 80 registers and the extra select spills: they keep the repeated address)
-    o.voff = (have || !OOR) ? (unsigned)px * ES + (unsigned)cg * (UNIT == kUnitMx ? 1u : 4u) * (unsigned)(H * W) * ES : kOffRange;
-    const unsigned slot = UNIT == kUnitMx ? (unsigned)(cg * u.pu + row * u.pitch + 4 * q) : (unsigned)((row * u.pitch + 4 * q) * UNIT + cg);
-    o.meta = slot | (xmask << 13) | (have ? 1u << 17 : 0u) | (row_in ? 1u << 18 : 0u);
+    o.voff = (have || !OOR) ? (unsigned)px * ES + (unsigned)cg * 4u * (unsigned)(H * W) * ES : kOffRange;
+    o.meta = (unsigned)((row * u.pitch + 4 * q) * UNIT + cg) | (xmask << 13) | (have ? 1u << 17 : 0u) | (row_in ? 1u << 18 : 0u);
     return o;
 }
 
@@ -131,18 +125,18 @@ __device__ __forceinline__ void quad_issue(QuadRegs<N, FT> &r, rsrc_t f1r, unsig
         const bool real = !OOR || n == 0 || (wave + 8 * (k0 + n)) * 16 < u.h * u.nq;
         if (real) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * (UNIT == kUnitMx ? 4u : 1u) * plane4);
+            for (int j = 0; j < 4; ++j) r.a[n][j] = QuadRaw<FT>::load(f1r, vo, so + (unsigned)j * plane4);
         }
     }
 }
 
-template <int N, bool CHECK, typename FT, int UNIT = kSlotV4>
+template <int N, bool CHECK, typename FT>
 __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r, int H, int W, const RowPlan &u, int wave, int lane,
                                             const QuadLane &ql, int k0) {
     const int ipw = u.nitems >> 3;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-        const unsigned meta = (k0 == 0 && n < kQuadPre) ? ql.it[n].meta : quad_item<CHECK, FT, UNIT>(u, H, W, wave, lane, k0 + n).meta;
+        const unsigned meta = (k0 == 0 && n < kQuadPre) ? ql.it[n].meta : quad_item<CHECK, FT>(u, H, W, wave, lane, k0 + n).meta;
         if ((k0 + n < ipw) & ((meta >> 17) & 1u)) {
             float4 *dst = s4 + (meta & 0x1FFFu);
             unsigned m = 0xFu;
@@ -153,19 +147,19 @@ __device__ __forceinline__ void quad_commit(float4 *s4, const QuadRegs<N, FT> &r
             for (int k = 0; k < 4; ++k) {
                 float4 v = make_float4(w0[k], w1[k], w2[k], w3[k]);
                 if (CHECK && !((m >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[UNIT == kUnitMx ? k : k * kSlotV4] = v;
+                dst[k * kSlotV4] = v;
             }
         }
     }
 }
 
-template <bool CHECK, typename FT, int UNIT = kSlotV4>
+template <bool CHECK, typename FT>
 __device__ __forceinline__ void quad_rest(float4 *s4, rsrc_t f1r, unsigned chunk_off, int H, int W, const RowPlan &u, int wave, int lane,
                                           const QuadLane &ql, int done) {
     for (int k0 = done; k0 < (u.nitems >> 3); ++k0) {  // only regions of more than 256 quads (rare)
         QuadRegs<1, FT> r;
-        quad_issue<1, CHECK, FT, UNIT>(r, f1r, chunk_off, H, W, u, wave, lane, ql, k0);
-        quad_commit<1, CHECK, FT, UNIT>(s4, r, H, W, u, wave, lane, ql, k0);
+        quad_issue<1, CHECK, FT>(r, f1r, chunk_off, H, W, u, wave, lane, ql, k0);
+        quad_commit<1, CHECK, FT>(s4, r, H, W, u, wave, lane, ql, k0);
     }
 }
 
