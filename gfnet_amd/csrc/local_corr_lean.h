@@ -651,19 +651,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 template <int R>
 constexpr int lean_workers() { return (GFN_LEAN_INLINE_WORKERS && R >= 3) ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
 
+// one 4 x 16-cell tile `wid` from its plan record: the body of the tile kernel (also the fall-back of the 8 x 16-cell kernel of
+// local_corr_big.h for tile pairs that do not take its path)
 template <int R, int NCH, typename FT>
-__global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kLeanWorkers = lean_workers<R>();
-    if constexpr (kLeanWorkers > 0) {
-        if (blockIdx.x < kLeanWorkers) {  // block-uniform
-            second_launch_worker<R, 2, FT, Lean<R>::kStage>(p, smem, (int)blockIdx.x, kLeanWorkers);
-            return;
-        }
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wid = gfn::xcd_remap(blockIdx.x - kLeanWorkers, gridDim.x - kLeanWorkers);
+__device__ __forceinline__ void lean_small_tile(const LcParams &p, unsigned char *smem, unsigned wid, int tid, int lane, int wave) {
     // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
     // have in the vector-memory pipeline
     typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -700,4 +691,20 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
         if (interior) lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
         else lean_tile<R, NCH, true, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     }
+}
+
+template <int R, int NCH, typename FT>
+__global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2_kernel(LcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kLeanWorkers = lean_workers<R>();
+    if constexpr (kLeanWorkers > 0) {
+        if (blockIdx.x < kLeanWorkers) {  // block-uniform
+            second_launch_worker<R, 2, FT, Lean<R>::kStage>(p, smem, (int)blockIdx.x, kLeanWorkers);
+            return;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wid = gfn::xcd_remap(blockIdx.x - kLeanWorkers, gridDim.x - kLeanWorkers);
+    lean_small_tile<R, NCH, FT>(p, smem, wid, tid, lane, wave);
 }
