@@ -862,7 +862,6 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_irregular_kernel(LcPar
 }
 
 #include "local_corr_lean.h"
-#include "local_corr_big.h"
 #include "local_corr_mstage.h"
 #include "local_corr_mq.h"
 
@@ -932,15 +931,8 @@ int device_cu_count() {
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, unsigned flags) {
     (void)flags;
-    if constexpr (Big<R>::kOn) {   // 8 x 16-cell tiles: one workgroup per pair of vertically adjacent tiles (local_corr_big.h)
-        const unsigned pairs = (unsigned)p.B * (unsigned)p.tiles_x * (unsigned)((p.tiles_y + 1) / 2);
-        const size_t lds_big = lds > (size_t)Big<R>::kLds ? lds : (size_t)Big<R>::kLds;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_big_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        hipLaunchKernelGGL((local_corr_big_kernel<R, NCH, FT>), dim3(pairs + lean_workers<R>()), dim3(kThreads), lds_big, stream, p);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
 
 // the round-1 tile path: the staged tile kernel (r >= 5 on 64-channel maps: the matrix-core kernel of local_corr_mq.h) and the second
