@@ -28,6 +28,9 @@ constexpr int kMmNBW = 10;  // local_corr_mq.h: accumulator blocks per wave of t
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
+#ifndef GFN_LEAN_STAGE4_KB
+#define GFN_LEAN_STAGE4_KB 64
+#endif
 constexpr int kPlanInts = 16;  // per tile: region A x0, y0, (h << 16) | w, flags; region B x0, y0, (h << 16) | w, geometry of A;
                                // geometry of B, direction b, row0 | col0 << 16, spare ...  (geometry = pitch | quads per row << 8 | items << 16:
                                // round 4 -- the tile kernel no longer derives the regions' pitch and item count (region_fits) and the tile's
@@ -50,8 +53,13 @@ struct Lean {
     // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU.  r = 7: the D buffer that aliases the stage (64 cells x 257
     // floats) needs 65 792 bytes; with the f0 block staged chunk by chunk (kF0Chunk) the total stays at 80 160
     static constexpr int kDbuf = ((64 * ((2 * R + 2) * (2 * R + 2) + 1) + 16) * 4 + 15) & ~15;  // + 16: the skew of cells 32-63 (lean_tile)
-    static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : (kDbuf > 64 * 1024 ? kDbuf : 64 * 1024);
-    static constexpr bool kF0Chunk = R >= 5;  // 64-channel maps: 16 channels of the f0 block in LDS at a time (5 KB instead of 17)
+    // Round 5 experiment (-DGFN_LEAN_STAGE4_KB=68): r = 3 / 4 stage the f0 block chunk by chunk too (5 KB instead of 9 KB on 32-channel
+    // maps) and give the 4 KB to the stage, 870 positions instead of 819, so that the 7.4 % of the bench's scale-4 tiles whose regions
+    // are 44 x 19 = 836 pixels are staged whole instead of as two halves.  Measured SLOWER (bench flows 105.8 vs 102.7 us, homography
+    // flows 98.4 vs 95.7): the per-chunk f0 loads and filing cost every tile more than the halves cost the few.
+    static constexpr int kStage34 = GFN_LEAN_STAGE4_KB * 1024;
+    static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : (kDbuf > kStage34 ? kDbuf : kStage34);
+    static constexpr bool kF0Chunk = R >= 5 || (R >= 3 && GFN_LEAN_STAGE4_KB > 64);  // 16 channels of the f0 block in LDS at a time
     static constexpr int kCap = kStage / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;

@@ -29,6 +29,12 @@ def child():
         f1 = torch.randn(B, c, hs, hs, generator=g).cuda()
         if kind == "homography":
             flow = torch.from_numpy(np.tile(synth.homography_flow(2, G, 5), (B // 2, 1, 1, 1))).cuda()
+        elif kind == "bench":  # the bench's flows: true warps of 15 % corner-perturbation homographies (both directions) + 0.5-px noise
+            from gfnet_amd import _synthetic as synthetic
+            S = 4 * hs if r == 4 else (2 * hs if r == 2 else 8 * hs)
+            Hm = synthetic.random_homographies(B // 2, S, g)
+            flow = torch.cat((synthetic.warp_grid(Hm, G, S, "cpu"), synthetic.warp_grid(np.linalg.inv(Hm), G, S, "cpu"))).permute(0, 3, 1, 2)
+            flow = (flow + torch.randn(B, 2, G, G, generator=g) * (0.5 / S)).contiguous().cuda()
         elif kind == "sprinkle":  # the bench's situation: smooth flows, a handful of tiles per launch left to the second launch
             flow = torch.from_numpy(np.tile(synth.homography_flow(2, G, 5), (B // 2, 1, 1, 1)))
             for k in range(3):
