@@ -973,7 +973,7 @@ int launch_lean_path(const LcParams &p0, hipStream_t stream) {
     constexpr int NC = 64;
     const unsigned total = (unsigned)p.B * p.tiles_x * p.tiles_y;
     if ((size_t)p.todo_ints < (size_t)total + kTodoHdr) return gfn::fail(GFN_ERR_SCRATCH, "local_corr: scratch too small");
-    const size_t lds2 = Lean<R>::kStage + ((NC * 20 + 32 + 15) & ~15) + (((NC * (2 * (2 * R + 1) + 1) + 16) * 4 + 15) & ~15) +  // + 16: the table's skew (lean_tile)
+    const size_t lds2 = Lean<R>::kStageLds + ((NC * 20 + 32 + 15) & ~15) + (Lean<R>::kTabInStage ? 0 : Lean<R>::kTabBytes) +  // (the table: inside the stage at r = 3, 4)
                         (size_t)NC * ((Lean<R>::kF0Chunk ? kChunk : p.C) + 4) * 4;
     if (lds2 > kMaxLds) return -1000;
     if (!p.planned) {

@@ -28,6 +28,9 @@ constexpr int kMmNBW = 10;  // local_corr_mq.h: accumulator blocks per wave of t
 #ifndef GFN_LEAN_STAGE2_KB
 #define GFN_LEAN_STAGE2_KB 40
 #endif
+#ifndef GFN_LEAN_TAB_IN_STAGE
+#define GFN_LEAN_TAB_IN_STAGE 1
+#endif
 #ifndef GFN_LEAN_STAGE4_KB
 #define GFN_LEAN_STAGE4_KB 64
 #endif
@@ -60,7 +63,16 @@ struct Lean {
     static constexpr int kStage34 = GFN_LEAN_STAGE4_KB * 1024;
     static constexpr int kStage = R <= 2 ? GFN_LEAN_STAGE2_KB * 1024 : (kDbuf > kStage34 ? kDbuf : kStage34);
     static constexpr bool kF0Chunk = R >= 5 || (R >= 3 && GFN_LEAN_STAGE4_KB > 64);  // 16 channels of the f0 block in LDS at a time
-    static constexpr int kCap = kStage / (kSlotV4 * 16);
+    // Round 5: r >= 3 keep the fraction table (64 cells x 19 floats) INSIDE the stage, behind the D buffer: it is filled after the main
+    // loop (measured level with filling it up front, GFN_LEAN_TABLE_LATE above), when the stage holds nothing else, and its 5 KB go to
+    // the stage instead -- 881 positions instead of 819 at r = 4: the 44 x 19-pixel regions of the bench's flows (7.4 % of the
+    // scale-4 tiles) are staged whole instead of as two halves.  The workgroup's LDS total is unchanged.
+    static constexpr bool kTabInStage = GFN_LEAN_TAB_IN_STAGE != 0 && R >= 3 && R <= 4;
+    static constexpr int kTabBytes = ((64 * (2 * (2 * R + 1) + 1) + 16) * 4 + 15) & ~15;
+    static constexpr int kStageLds = kStage + (kTabInStage ? kTabBytes : 0);   // bytes of LDS the stage spans
+    static constexpr int kTabOff = (kDbuf + 15) & ~15;                         // table offset inside the stage (kTabInStage)
+    static_assert(!kTabInStage || kTabOff + kTabBytes <= kStageLds, "the late table lies behind the D buffer");
+    static constexpr int kCap = kStageLds / (kSlotV4 * 16);
     static constexpr int kMinWaves = (R <= 2 && GFN_LEAN_STAGE2_KB <= 44) ? 6 : 4;  // waves per SIMD the register allocation must allow
     static constexpr int PW = 2 * R + 2;
 };
@@ -271,7 +283,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
                                           int tid, int lane, int wave) {
     constexpr int ROUNDS = 2;
     constexpr int C = 16 * NCH;
-    constexpr int kStageBytes = Lean<R>::kStage;  // shadows the round-1 constant
+    constexpr int kStageBytes = Lean<R>::kStageLds;  // shadows the round-1 constant
+    constexpr bool kTabIn = Lean<R>::kTabInStage;
     constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
     constexpr int D = 2 * R + 1, K = D * D;
     constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
@@ -293,8 +306,9 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     int *hdr = cellFlag + NC;                                  // [4]: number of flagged cells
     constexpr int kCellBytes = (NC * 20 + 32 + 15) & ~15;
     constexpr int kTabBytes = ((NC * TS + kSkew) * 4 + 15) & ~15;
-    float *tab = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes);   // [NC][TS] per-tap fractions
-    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + kTabBytes);  // [NC][C + 4]: the tile's f0, cell-major
+    static_assert(kTabBytes == Lean<R>::kTabBytes, "table size");
+    float *tab = reinterpret_cast<float *>(kTabIn ? smem + Lean<R>::kTabOff : smem + kStageBytes + kCellBytes);   // [NC][TS] per-tap fractions
+    float *f0s = reinterpret_cast<float *>(smem + kStageBytes + kCellBytes + (kTabIn ? 0 : kTabBytes));  // [NC][C + 4]: the tile's f0, cell-major
 
     const int G = p.G, H = p.H, W = p.W;
     const float xhi = p.win_xhi, xlo = -xhi, yhi = p.win_yhi, ylo = -yhi;
@@ -468,7 +482,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #ifndef GFN_LEAN_TABLE_LATE
 #define GFN_LEAN_TABLE_LATE 0  // measured level (r = 4: 96.5 vs 96.3 us, r = 2: 150.3 vs 153.9): the tile kernels are bound by what they issue, not by where in the tile it sits
 #endif
-    constexpr bool kTableLate = GFN_LEAN_TABLE_LATE != 0 && !kFlowAll;
+    constexpr bool kTableLate = (GFN_LEAN_TABLE_LATE != 0 || kTabIn) && !kFlowAll;
+    static_assert(!kTabIn || !kFlowAll, "the table in the stage is filled behind the main loop");
     if (!kTableLate) {
         if (!kFlowAll && !ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
         if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
@@ -549,12 +564,16 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     }
 
     // ---- epilogue: D -> LDS, bilinear combination, coalesced stores ----------------------------------------------------
-    if (kTableLate) {
+    if (kTableLate && !kTabIn) {
         if (!ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
         if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
     }
     __syncthreads();
     STAMP(10);
+    if (kTabIn) {   // behind the barrier: nobody reads staged pixels any more, the table goes where they were (beside the D buffer)
+        if (!ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
+        if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
+    }
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
@@ -707,7 +726,7 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     constexpr int kLeanWorkers = lean_workers<R>();
     if constexpr (kLeanWorkers > 0) {
         if (blockIdx.x < kLeanWorkers) {  // block-uniform
-            second_launch_worker<R, 2, FT, Lean<R>::kStage>(p, smem, (int)blockIdx.x, kLeanWorkers);
+            second_launch_worker<R, 2, FT, Lean<R>::kStage>(p, smem, (int)blockIdx.x, kLeanWorkers);  // (its own LDS layout inside the same allocation)
             return;
         }
     }
