@@ -603,6 +603,9 @@ int launch_fused_mt(const float *x, const float *packed, float *y, int B, int M,
     if (nwork > 0x7fffffffL) return gfn::fail(GFN_ERR_INVALID_ARG, "conv_block: too many tiles");
     // work items per workgroup (pipelined back to back)
     int tpb = nwork >= 16384 ? 2 : 1;  // measured: pays only on the largest grids
+#ifdef GFN_CONV_TPB_FORCE  // A/B builds (python -m gfnet_amd.build --variant NAME --src conv_stack_half.hip -DGFN_CONV_TPB_FORCE=4)
+    if (nwork >= 16384) tpb = GFN_CONV_TPB_FORCE;
+#endif
     if (g_conv_tpb > 0) tpb = g_conv_tpb;
     const unsigned grid = (unsigned)((nwork + tpb - 1) / tpb);
     hipLaunchKernelGGL((dwpw_fused_kernel<MT, TW, NS, F16, NB, HIN, HOUT, MM, KW>), dim3(grid), dim3(256 * NS), 0, s, x, packed, y, M, K, G, tiles_x,

@@ -230,3 +230,20 @@ def test_gfnet_loads_a_full_reference_checkpoint():
     assert "merge_layer.0.weight" not in dst2.ignored_backbone_keys
     with pytest.raises(RuntimeError):
         dst.load_state_dict(dict(ckpt, bogus=torch.zeros(1)))
+
+
+def test_refiner_keeps_the_flags_the_reference_stores_without_reading_them():
+    """The reference's ConvRefiner takes no_im_B_fm / concat_logits / use_cosine_corr / disable_local_corr_grad / is_classifier, stores
+    them (network.py:496-501) and its forward (network.py:533-564) never reads one of them.  The mirror does the same: a constructor call
+    written for the reference builds the same module, the flags are attributes without effect (rounds 1-4 raised NotImplementedError)."""
+    from gfnet_amd.model.network import ConvRefiner
+
+    kw = dict(dw=True, hidden_blocks=1, displacement_emb="linear", displacement_emb_dim=2, local_corr_num=1, corr_in_other=True)
+    torch.manual_seed(0)
+    plain = ConvRefiner(10, 10, 3, **kw)
+    torch.manual_seed(0)
+    flagged = ConvRefiner(10, 10, 3, no_im_B_fm=True, concat_logits=True, use_cosine_corr=True, disable_local_corr_grad=True, is_classifier=True, **kw)
+    assert flagged.no_im_B_fm and flagged.concat_logits and flagged.use_cosine_corr and flagged.disable_local_corr_grad and flagged.is_classifier
+    assert list(plain.state_dict()) == list(flagged.state_dict())
+    for (k, a), b in zip(plain.state_dict().items(), flagged.state_dict().values()):
+        assert torch.equal(a, b), k

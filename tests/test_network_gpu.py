@@ -256,15 +256,6 @@ def test_refiner_training_mode_backpropagates_like_the_reference():
     assert dflow.requires_grad and torch.autograd.grad(dflow.sum() + dcert.sum(), x)[0].abs().sum() > 0
 
 
-def test_refiner_rejects_flags_it_does_not_implement():
-    from gfnet_amd.model.network import ConvRefiner
-
-    for flag in ("no_im_B_fm", "concat_logits", "use_cosine_corr", "is_classifier"):
-        with pytest.raises(NotImplementedError):
-            ConvRefiner(10, 10, 3, dw=True, hidden_blocks=0, displacement_emb="linear", displacement_emb_dim=2, local_corr_num=1,
-                        corr_in_other=True, **{flag: True})
-
-
 def test_scratch_is_dropped_after_a_failed_call_and_streams_do_not_share_it():
     from gfnet_amd import _lib
     from gfnet_amd.utils.local_correlation import local_correlation
