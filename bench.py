@@ -643,7 +643,52 @@ def main():
             torch.cuda.synchronize()
             n2 = max(3, min(args.steps, 10))
             dt2, _ = timed_loop(lambda i: runner2.step(0), n2, torch.cuda.synchronize)
+            # second roofline object: the conv blocks of three more one-stream steps, HIP events around every
+            # gfn_conv_block_half_fwd call, grouped by (channels, grid): the wide blocks against the dense fp16 MFMA peak, the narrow
+            # ones against HBM on their map bytes (half map in + half map out)
+            class _Conv(dict):
+                def __contains__(self, k):
+                    return k.startswith("conv_block_half_")
+
+                def __missing__(self, k):
+                    self[k] = []
+                    return self[k]
+
+            plain2 = SceneRunner(scenes2, pipeline=False)
+            plain2.step(0)
+            torch.cuda.synchronize()
+            ops.kernel_events = _Conv()
+            for i in range(3):
+                plain2.step(0)
+            torch.cuda.synchronize()
+            cev, ops.kernel_events = ops.kernel_events, None
+            conv_rows, conv_us = [], 0.0
+            for name, evs in cev.items():
+                Cc, Gc = (int(v[1:]) for v in name.split("_")[3:5])
+                us_ = float(np.mean([a.elapsed_time(b_) for a, b_ in evs])) * 1e3
+                nb = 2 * B   # directions per call
+                flop = 2.0 * nb * Gc * Gc * (Cc * Cc + 25 * Cc)
+                map_bytes = 2.0 * nb * ((Cc + 1) // 2) * Gc * Gc * 4
+                conv_us += us_ * len(evs) / 3
+                conv_rows.append({"channels": Cc, "grid": Gc, "calls_per_step": round(len(evs) / 3, 2), "avg_launch_us": round(us_, 1),
+                                  "tflops": round(flop / us_ / 1e6, 1), "frac_of_fp16_mfma_peak_2500": round(flop / us_ / 1e6 / 2500.0, 4),
+                                  "map_tb_per_s": round(map_bytes / us_ / 1e6, 2), "frac_of_hbm_8tbs": round(map_bytes / us_ / 1e6 / 8.0, 3)})
+            conv_rows.sort(key=lambda r_: -r_["avg_launch_us"] * r_["calls_per_step"])
+            wide = [r_ for r_ in conv_rows if r_["channels"] >= 128]
+            narrow = [r_ for r_ in conv_rows if r_["channels"] < 128]
+            wsum = sum(r_["avg_launch_us"] * r_["calls_per_step"] for r_ in wide) or 1.0
+            nsum = sum(r_["avg_launch_us"] * r_["calls_per_step"] for r_ in narrow) or 1.0
+            conv_roofline = {"what": "fused conv blocks (depthwise 5x5 + BatchNorm + ReLU + 1x1, fp16 maps) of a step, per (channels, grid); blocks whose "
+                                     "first input is the fp32 concat or whose output is the 3-channel fp32 head count with the map bytes of a half map pair "
+                                     "(an under-estimate of their traffic)",
+                             "conv_us_per_step": round(conv_us, 1),
+                             "wide_blocks": {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "us_per_step": round(wsum, 1),
+                                             "frac_time_weighted": round(sum(r_["frac_of_fp16_mfma_peak_2500"] * r_["avg_launch_us"] * r_["calls_per_step"] for r_ in wide) / wsum, 4)},
+                             "narrow_blocks": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "us_per_step": round(nsum, 1),
+                                               "frac_time_weighted": round(sum(r_["frac_of_hbm_8tbs"] * r_["avg_launch_us"] * r_["calls_per_step"] for r_ in narrow) / nsum, 3)},
+                             "rows": conv_rows}
             stack_leg = {"value": round(pairs_per_step * n2 / dt2, 2), "unit": "pairs/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
+                         "conv_roofline": conv_roofline,
                          "step_pipeline": "as the timed region" if args.pipeline else "off",
                          "refiner_conv_stack": "reference architecture, random-init, HIP conv_stack kernels, conv_precision='amp' (fp16 maps, "
                                                "fp16 operands, fp32 accumulation: model/network.py:560-562)"}
