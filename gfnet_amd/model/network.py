@@ -21,6 +21,7 @@ torch.autocast -- fp16 maps between the blocks); training mode keeps the nn modu
 differentiable torch ops (the HIP assembly has no backward).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -246,6 +247,13 @@ class GFNet(nn.Module):
         self.num_grid = list(m["num_grid"])
         self.radius = list(m["radius"])
         self.num_itr = list(m["num_itr"])
+        self.backbone_state, self.ignored_backbone_keys = {}, []
+        if backbone is None and os.environ.get("GFNET_COMPAT_BACKBONE", "") == "reference":
+            # the reference's own constructor call (test.py:25-30) has no backbone argument: with this switch the DINOv2 + decoder + FPN
+            # of the user's checkout are assembled here, as the reference's constructor does (network.py:44-65)
+            from ..reference_backbone import reference_backbone
+
+            backbone = reference_backbone(conf, amp=amp, amp_dtype=amp_dtype)
         self.backbone = backbone
         if conv_refiner is None:
             chs = conf["encoder_cfg"]["feat_chs"]  # coarse to fine: [64, 32, 16, 8]
@@ -271,22 +279,43 @@ class GFNet(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         """Accepts a FULL reference checkpoint (test.py:37-38: `model.load_state_dict(states["model"])`): `conv_refiner.*` entries load
-        as they are (same parameter names); an entry of the reference's backbone goes to `backbone.<name>` when the injected backbone
-        is a module that has it, and is set aside otherwise (`self.ignored_backbone_keys`; the backbone is host code outside this
-        package).  Anything else is reported by torch as usual."""
+        as they are (same parameter names); an entry of the reference's backbone goes to `backbone.<name>` when the attached backbone
+        is a module that has it.  Without such a module the entries are NOT dropped: they are kept (`self.backbone_state`, names in
+        `self.ignored_backbone_keys`), a warning says how many, and they are loaded the moment a backbone module is assigned to
+        `model.backbone` (construct -> load_state_dict -> assign the backbone must not leave it at its random init).
+        Anything else is reported by torch as usual."""
         own = self.state_dict()
-        routed, ignored = {}, []
+        routed, pending = {}, {}
         for k, v in state_dict.items():
             if k in own:
                 routed[k] = v
             elif "backbone." + k in own:
                 routed["backbone." + k] = v
             elif k.split(".")[0] in self.REFERENCE_BACKBONE_PREFIXES:
-                ignored.append(k)
+                pending[k] = v
             else:
                 routed[k] = v
-        self.ignored_backbone_keys = ignored
+        self.backbone_state = pending
+        self.ignored_backbone_keys = list(pending)
+        if pending:
+            import warnings
+
+            prefixes = sorted({k.split(".")[0] for k in pending})
+            warnings.warn(f"GFNet.load_state_dict: {len(pending)} backbone entries ({', '.join(prefixes)}.*) have no module to go to yet; "
+                          "they are kept in model.backbone_state and are loaded when an nn.Module backbone with those submodules is "
+                          "assigned to model.backbone (a plain callable backbone has to load its own weights)", stacklevel=2)
         return super().load_state_dict(routed, strict=strict, assign=assign)
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "backbone" and isinstance(value, nn.Module) and getattr(self, "backbone_state", None):
+            # the checkpoint came first (test.py's order with a backbone attached afterwards): hand the kept entries over now
+            have = value.state_dict()
+            take = {k: v for k, v in self.backbone_state.items() if k in have}
+            if take:
+                value.load_state_dict(take, strict=False)
+            self.backbone_state = {k: v for k, v in self.backbone_state.items() if k not in take}
+            self.ignored_backbone_keys = list(self.backbone_state)
 
     # ---- the two methods GFNet.forward calls at scale 16 (network.py:251-252) -------------------
     def corr_volume(self, feat0, feat1):
