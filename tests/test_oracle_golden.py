@@ -151,15 +151,71 @@ def test_g4_conv_stack_matches_reference():
     assert_close(out1[:, 2:3], g["delta_cert_nocorr"], 1e-6, "delta_cert (no corr)")
 
 
-# ---- G5 (interpolate part) / G6: match post-processing (model/network.py:326-384) -------------
-def test_interpolate_matches_forward_loop_golden():
+# ---- G5: the forward loop (model/network.py:203-283) / G6: match post-processing (model/network.py:326-384) -------------
+def _walk_forward_loop(g, pyr0, pyr1, scales, grids, radii, itrs, size, scale_factor=1.0, pre=None):
+    """GFNet.forward (model/network.py:203-283, symmetric=True) restated with the oracle's pieces only: corr_softargmax (:251-252),
+    refiner_input (:533-558), conv_stack (:560-563), flow_update (:262-268), interpolate_bilinear (:238-249, :271-281)."""
+    f0 = {s: np.concatenate((pyr0[s], pyr1[s])) for s in scales}   # :213-222
+    f1 = {s: np.concatenate((pyr1[s], pyr0[s])) for s in scales}
+    out = {}
+    for i, s in enumerate(scales):
+        if i == 0:
+            if pre is None:
+                flow = oracle.corr_softargmax(f0[s], f1[s])
+                cert = np.zeros((flow.shape[0], 1) + flow.shape[2:], np.float32)
+            else:
+                flow, cert = oracle.interpolate_bilinear(pre[0], grids[0]), oracle.interpolate_bilinear(pre[1], grids[0])
+        sd = {k[len(f"sd.{s}."):]: g[k] for k in g.files if k.startswith(f"sd.{s}.")}
+        disp_prev = np.full_like(flow, 1e-7)                         # :256
+        for itr in range(itrs[i]):
+            d = oracle.refiner_input(grids[i], f0[s], f1[s], flow, sd["disp_emb.weight"], sd["disp_emb.bias"], radii[i],
+                                     scale_factor=scale_factor, corr_in_other=radii[i] > 0)
+            delta = oracle.conv_stack(d, sd)
+            flow, cert, disp_prev, rel = oracle.flow_update(flow, cert, delta[:, :2], delta[:, 2:3], disp_prev, int(s), size, size,
+                                                            return_rel=True)
+            out[(s, itr + 1)] = (flow, cert, rel)
+        if s != "1":
+            flow, cert = oracle.interpolate_bilinear(flow, grids[i + 1]), oracle.interpolate_bilinear(cert, grids[i + 1])
+    return out
+
+
+def test_g5_forward_loop_walked_by_the_oracle_both_passes():
+    """The oracle's loop bookkeeping pinned DIRECTLY on the reference's own forward() (it was pinned only through
+    'HIP == G5' and 'HIP == oracle'): every flow / certainty of every scale and iteration of the first pass and of the upsample pass
+    (seeded from the first pass's finest result, scale_factor 1.25, num_itr_up[0] = 2), 1e-6.  Cells where the eval-time zeroing rule
+    (:264-265, |d - d_prev| / |d_prev| < 1e-6) is decided within a factor 10 of its threshold are exempt at that step (a handful of components; they agree too on this build's numpy, the mask only keeps a
+    last-bit difference of another BLAS from failing the suite)."""
     g = load_golden("g5_forward_loop")
-    # upsample pass seeds its flow by resizing the finest flow of the first pass to num_grid_up[0]
-    # (network.py:238-249); with num_itr_up[0]=2 the refiner changes it, so check the resize on its own
-    # through G6's attenuation path instead and check plain shapes here.
-    f = g["flow.1.1"]
-    out = oracle.interpolate_bilinear(f, 5)
-    assert out.shape == (f.shape[0], 2, 5, 5)
+    scales = ["16", "8", "4", "2", "1"]
+    radii = [int(v) for v in g["radius"]]
+    pyr0 = {s: g[f"pyr0.{s}"] for s in scales}
+    pyr1 = {s: g[f"pyr1.{s}"] for s in scales}
+    size = pyr0["1"].shape[-1]
+    first = _walk_forward_loop(g, pyr0, pyr1, scales, [int(v) for v in g["num_grid"]], radii, [int(v) for v in g["num_itr"]], size)
+    n = 0
+    for (s, itr), (flow, cert, rel) in first.items():
+        keep = ~((rel > 1e-7) & (rel < 1e-5))
+        assert keep.mean() > 0.97
+        assert_close(np.where(keep, flow, 0), np.where(keep, g[f"flow.{s}.{itr}"], 0), 1e-6, f"flow {s}/{itr}")
+        assert_close(cert, g[f"cert.{s}.{itr}"], 1e-6, f"cert {s}/{itr}")
+        n += 1
+    assert n == sum(int(v) for v in g["num_itr"])
+    up_scales = scales[1:]
+    up0 = {s: g[f"up0.{s}"] for s in up_scales}
+    up1 = {s: g[f"up1.{s}"] for s in up_scales}
+    # seeded by the REFERENCE's finest correspondences (what forward() was handed, make_golden.py g5) -- and, separately, by the
+    # oracle's own: the second makes the two passes one uninterrupted oracle walk
+    for seed in ((g["flow.1.1"], g["cert.1.1"]), first[("1", 1)][:2]):
+        second = _walk_forward_loop(g, up0, up1, up_scales, [int(v) for v in g["num_grid_up"]], radii[1:],
+                                    [int(v) for v in g["num_itr_up"]], up0["1"].shape[-1], scale_factor=1.25, pre=seed)
+        n = 0
+        for (s, itr), (flow, cert, rel) in second.items():
+            keep = ~((rel > 1e-7) & (rel < 1e-5))   # one component of one cell sits in the band (scale 8, second iteration)
+            assert keep.mean() > 0.97
+            assert_close(np.where(keep, flow, 0), np.where(keep, g[f"upflow.{s}.{itr}"], 0), 2e-6, f"upflow {s}/{itr}")
+            assert_close(cert, g[f"upcert.{s}.{itr}"], 2e-6, f"upcert {s}/{itr}")
+            n += 1
+        assert n == sum(int(v) for v in g["num_itr_up"])
 
 
 @pytest.mark.parametrize("tag,symmetric,attenuate", [("sym_up_att", True, True), ("plain", False, False),
