@@ -104,10 +104,15 @@ if __name__ == "__main__":
     if "--ablate" in sys.argv:
         print(build_ablate(verbose=True))
         sys.exit(0)
-    if "--variant" in sys.argv:  # python -m gfnet_amd.build --variant NAME [--src file.hip] -DFOO=1 ...
+    if "--variant" in sys.argv:  # python -m gfnet_amd.build --variant NAME [--src file.hip] <compiler flags, passed through verbatim>
         i = sys.argv.index("--variant")
-        src_name = sys.argv[sys.argv.index("--src") + 1] if "--src" in sys.argv else "local_corr.hip"
-        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-m")], src_name, verbose=True))
+        rest = sys.argv[i + 2:]
+        src_name = "local_corr.hip"
+        if "--src" in rest:
+            j = rest.index("--src")
+            src_name = rest[j + 1]
+            rest = rest[:j] + rest[j + 2:]
+        print(build_variant(sys.argv[i + 1], rest, src_name, verbose=True))  # (`-mllvm <opt>` keeps its value token: ADVICE r5)
         sys.exit(0)
     extra = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
     print(build(force="--force" in sys.argv, verbose=True, extra=extra))

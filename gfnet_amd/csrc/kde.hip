@@ -500,7 +500,8 @@ __global__ __launch_bounds__(kKdeThreads, 4) void kde4_mfma_kernel(const float *
             const bool s00 = (m00 >> bit) & 1, s01 = (m01 >> bit) & 1, s10 = (m10 >> bit) & 1, s11 = (m11 >> bit) & 1;  // scalar
             // column tile 0 then column tile 1, each: MFMAs, then its exponentials -- the products of the two tiles share
             // registers (4 waves per SIMD instead of 3); other waves' exponentials run under this wave's MFMAs
-            f32x2 cs0 = f32x2{0.f, 0.f}, cs1 = f32x2{0.f, 0.f};  // SYM: this lane's column of the two column tiles
+            float cs0 = 0.f, cs1 = 0.f;  // SYM: this lane's column of the two column tiles (one register each: the pair sums are folded
+                                         // per column tile -- as f32x2 they were 4 more live registers and the kernel spilled 5 at 128)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const bool sa = ct ? s01 : s00, sb = ct ? s11 : s10;
@@ -531,11 +532,11 @@ __global__ __launch_bounds__(kKdeThreads, 4) void kde4_mfma_kernel(const float *
                         if (SYM) cs += x;
                     }
                 }
-                if (ct) cs1 = cs; else cs0 = cs;
+                if (ct) cs1 = cs.x + cs.y; else cs0 = cs.x + cs.y;
             }
             if (SYM && cur != qblk) {  // wave-uniform
                 // rows 4kh.. of both row tiles are in this lane, the other half of the rows in lane ^ 32
-                float s0 = cs0.x + cs0.y, s1 = cs1.x + cs1.y;
+                float s0 = cs0, s1 = cs1;
                 s0 += __shfl_xor(s0, 32);
                 s1 += __shfl_xor(s1, 32);
                 const float sv = kh ? s1 : s0;  // lanes 0-31: column tile 0, lanes 32-63: column tile 1
@@ -549,13 +550,20 @@ __global__ __launch_bounds__(kKdeThreads, 4) void kde4_mfma_kernel(const float *
     }
     // sum the 32 columns (lanes with the same kh), then lanes col == 0 hold rows (r&3) + 8(r>>2) + 4kh of each row tile
     float *dst = part + ((size_t)bt * MS + ms) * N;
+    // the butterfly's five permute indices are worked out HERE, from a lane id the compiler cannot trace back: with __shfl_xor it
+    // computed them in front of the main loop and carried them across it in scratch (5 spilled registers at the 128 cap)
+    int lane_late = lane;
+    asm volatile("" : "+v"(lane_late));
+    auto xor_lane = [&](float v, int o) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((lane_late ^ o) << 2, __float_as_int(v)));
+    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v0 = acc0[r >> 1][r & 1], v1 = acc1[r >> 1][r & 1];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
-            v0 += __shfl_xor(v0, o);
-            v1 += __shfl_xor(v1, o);
+            v0 += xor_lane(v0, o);
+            v1 += xor_lane(v1, o);
         }
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (col == 0 && q0 + row < N) dst[q0 + row] = v0;

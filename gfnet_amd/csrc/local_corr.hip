@@ -929,8 +929,10 @@ int device_cu_count() {
 }
 
 template <int R, int NCH, typename FT>
-void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream, unsigned flags) {
-    (void)flags;
+void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
+#ifdef GFN_LEAN_LDS_PAD_KB  // occupancy experiment (round 6, profiles/r06_local_corr_pairs.md): pad the allocation so that fewer workgroups fit a CU
+    lds += (size_t)GFN_LEAN_LDS_PAD_KB * 1024;
+#endif
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }
@@ -980,11 +982,11 @@ int launch_lean_path(const LcParams &p0, hipStream_t stream) {
         hipLaunchKernelGGL((local_corr_plan_kernel<R>), dim3((total + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave)), dim3(256), 0, stream, p);
         if (int e = gfn::check_launch("local_corr_plan_kernel")) return e;
     }
-    auto tiles = [&](unsigned flags) {
+    auto tiles = [&]() {
         switch (p.C) {  // the lean kernel is specialised on the number of 16-channel chunks
-            case 16: launch_lean<R, 1, FT>(p, total, lds2, stream, flags); break;
-            case 32: launch_lean<R, 2, FT>(p, total, lds2, stream, flags); break;
-            default: launch_lean<R, 4, FT>(p, total, lds2, stream, flags); break;
+            case 16: launch_lean<R, 1, FT>(p, total, lds2, stream); break;
+            case 32: launch_lean<R, 2, FT>(p, total, lds2, stream); break;
+            default: launch_lean<R, 4, FT>(p, total, lds2, stream); break;
         }
         return gfn::check_launch("local_corr_tile2_kernel");
     };
@@ -997,11 +999,11 @@ int launch_lean_path(const LcParams &p0, hipStream_t stream) {
         hipLaunchKernelGGL((local_corr_irregular_kernel<R, 2, FT>), dim3(grid2), dim3(kThreads), lds, stream, p);
         return gfn::check_launch("local_corr_irregular_kernel");
     };
-    if (lean_workers<R>() > 0) return tiles(0);  // its first workgroups are the second launch
+    if (lean_workers<R>() > 0) return tiles();  // its first workgroups are the second launch
     // (Round 5: marking the tile kernel hipExtAnyOrderLaunch behind a second launch issued first -- the two are independent, the plan
     // launch wrote the list -- does not make them run side by side on gfx950: 107.2 vs 108.5 us with three tiles listed, the flag is
     // documented as unsupported on GFX9.)
-    if (int e = tiles(0)) return e;
+    if (int e = tiles()) return e;
     return second();
 }
 

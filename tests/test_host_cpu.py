@@ -174,6 +174,16 @@ def test_product_kernels_keep_their_register_budget():
                 seen += 1
                 assert vgpr <= 128 and spill == 0, line  # two workgroups of eight waves per CU
     assert seen >= 12
+    # the matrix-core KDE kernels (0.35 ms of a 448b32 step): no spills in either form (round 6: the symmetric one carried the five
+    # permute indices of its final butterfly across the main loop in scratch)
+    kobj = os.path.join(ROOT, "gfnet_amd", "csrc", "kde.o")
+    kout = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_regs.py"), kobj, "kde4_mfma_kernel"], capture_output=True, text=True,
+                          check=True).stdout
+    klines = [ln for ln in kout.splitlines() if "kde4_mfma_kernel" in ln]
+    assert len(klines) >= 2
+    for ln in klines:
+        m = re.search(r"vgpr\s+(\d+) spill\s+(\d+).*?scratch\s+(\d+)", ln)
+        assert int(m.group(1)) <= 128 and int(m.group(2)) == 0 and int(m.group(3)) == 0, ln
 
 
 def test_compat_directory_resolves_the_reference_imports():
