@@ -930,9 +930,6 @@ int device_cu_count() {
 
 template <int R, int NCH, typename FT>
 void launch_lean(const LcParams &p, unsigned total, size_t lds, hipStream_t stream) {
-#ifdef GFN_LEAN_LDS_PAD_KB  // occupancy experiment (round 6, profiles/r06_local_corr_pairs.md): pad the allocation so that fewer workgroups fit a CU
-    lds += (size_t)GFN_LEAN_LDS_PAD_KB * 1024;
-#endif
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(local_corr_tile2_kernel<R, NCH, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     hipLaunchKernelGGL((local_corr_tile2_kernel<R, NCH, FT>), dim3(total + lean_workers<R>()), dim3(kThreads), lds, stream, p);
 }

@@ -40,34 +40,10 @@ constexpr int kPlanInts = 16;  // per tile: region A x0, y0, (h << 16) | w, flag
                                // direction / position (two integer divisions) in front of its first load: ~120 of a wave's ~1 550 instructions)
 constexpr int kPlanV4 = kPlanInts / 4;
 __device__ __forceinline__ int plan_geometry(const RowPlan &u) { return u.pitch | (u.nq << 8) | (u.nitems << 16); }
-constexpr int kPlanInterior = 1, kPlanSecond = 2, kPlanHalves = 4, kPlanPairs = 8;
+constexpr int kPlanInterior = 1, kPlanSecond = 2, kPlanHalves = 4;
 // flags: kPlanInterior -- no staged pixel lies outside the image; kPlanSecond -- the tile is on the second launch's list;
 // kPlanHalves -- the windows of the whole tile do not fit the stage, those of its two 4 x 8-cell halves do: region A serves
 // cells 0-31, region B cells 32-63, staged one after the other (otherwise region A serves all 64 cells)
-
-// kPlanPairs (round 6) -- whole-tile staging AND every horizontally adjacent pair of cells (2k, 2k + 1) has its two patch origins within
-// PairBox<R>: the D-stage then runs on PAIRS (one staged pixel read feeds both cells, lean_tile<..., PAIR>); the region's pitch is
-// == PairBox<R>::BW (mod 16) instead of == PW
-
-// Round 6: two cells per lane.  A pair's "box" is BW x BH pixels from the minimum of the two patch origins; it holds both (2r + 2)^2
-// patches whenever the origins differ by <= 3 columns and <= 1 row (every tile of the bench's scale-4 and scale-2 calls: the cell
-// spacing is 1.75 map pixels).  The box has NPB x 16 positions, a lane owns positions s + 16 t of its pair's box as it owns those of
-// a cell's patch in the single-cell D-stage.
-#ifndef GFN_LEAN_PAIRS
-#define GFN_LEAN_PAIRS 1
-#endif
-template <int R>
-struct PairBox {
-    static constexpr int PW = 2 * R + 2;
-    static constexpr int BW = PW + 3, BH = PW + 1;
-    static constexpr int PB = BW * BH;               // 143 (r = 4), 99 (r = 3), 63 (r = 2): odd, so also the D-buffer stride
-    static constexpr int NPB = (PB + 15) / 16;       // 9 / 7 / 4 passes for TWO cells (single cells: 7 / 4 / 3 each)
-    static constexpr int kMaxOff = (BH - PW) * BW + (BW - PW);   // largest offset of a patch inside its pair's box (16 at r = 4)
-    static constexpr int DSB = (PB + kMaxOff) | 1;   // D-buffer stride of a cell: its box image is shifted so that the PATCH starts at kMaxOff (lean_tile)
-    // r = 2 stays on single cells: its 40 KB stage (512 positions) does not hold the regions at the pair pitch (== 9 mod 16: 41 x 14
-    // for the bench's 31 x 13-pixel regions; one tile in five would pair) and its D-stage is an eighth of the call (profiles/r05_ablate_lean.txt)
-    static constexpr bool kOn = GFN_LEAN_PAIRS != 0 && R >= 3 && R <= 4;
-};
 
 // cell id inside a tile -> (row, column): cells 0-31 are the left 4 x 8 half, 32-63 the right one
 __device__ __forceinline__ int cell_row(int c) { return (c & 31) >> 3; }
@@ -79,9 +55,7 @@ template <int R>
 struct Lean {
     // + cells, fraction table, f0 block <= 80 KB: two workgroups per CU.  r = 7: the D buffer that aliases the stage (64 cells x 257
     // floats) needs 65 792 bytes; with the f0 block staged chunk by chunk (kF0Chunk) the total stays at 80 160
-    static constexpr int kDbuf1 = ((64 * ((2 * R + 2) * (2 * R + 2) + 1) + 16) * 4 + 15) & ~15;  // + 16: the skew of cells 32-63 (lean_tile)
-    static constexpr int kDbuf2 = ((64 * PairBox<R>::DSB + 16) * 4 + 15) & ~15;                    // the D buffer of the paired D-stage: a box per cell
-    static constexpr int kDbuf = (PairBox<R>::kOn && kDbuf2 > kDbuf1) ? kDbuf2 : kDbuf1;
+    static constexpr int kDbuf = ((64 * ((2 * R + 2) * (2 * R + 2) + 1) + 16) * 4 + 15) & ~15;  // + 16: the skew of cells 32-63 (lean_tile)
     // Round 5 experiment (-DGFN_LEAN_STAGE4_KB=68): r = 3 / 4 stage the f0 block chunk by chunk too (5 KB instead of 9 KB on 32-channel
     // maps) and give the 4 KB to the stage, 870 positions instead of 819, so that the 7.4 % of the bench's scale-4 tiles whose regions
     // are 44 x 19 = 836 pixels are staged whole instead of as two halves.  Measured SLOWER (bench flows 105.8 vs 102.7 us, homography
@@ -91,7 +65,7 @@ struct Lean {
     static constexpr bool kF0Chunk = R >= 5 || (R >= 3 && GFN_LEAN_STAGE4_KB > 64);  // 16 channels of the f0 block in LDS at a time
     // Round 5: r >= 3 keep the fraction table (64 cells x 19 floats) INSIDE the stage, behind the D buffer: it is filled after the main
     // loop (measured level with filling it up front, GFN_LEAN_TABLE_LATE above), when the stage holds nothing else, and its 5 KB go to
-    // the stage instead -- 881 positions instead of 819 at r = 4: the 44 x 19-pixel regions of the bench's flows (7.4 % of the
+    // the stage instead -- 880 positions instead of 819 at r = 4: the 44 x 19-pixel regions of the bench's flows (7.4 % of the
     // scale-4 tiles) are staged whole instead of as two halves.  The workgroup's LDS total is unchanged.
     static constexpr bool kTabInStage = GFN_LEAN_TAB_IN_STAGE != 0 && R >= 3 && R <= 4;
     static constexpr int kTabBytes = ((64 * (2 * (2 * R + 1) + 1) + 16) * 4 + 15) & ~15;
@@ -139,11 +113,12 @@ __device__ __forceinline__ CellBox cell_box(bool ok, float nx, float ny, float x
 
 
 template <int R>
-__device__ __forceinline__ bool region_fits(RowPlan &u, int pw = Lean<R>::PW, bool strict = false) {
+__device__ __forceinline__ bool region_fits(RowPlan &u) {
+    constexpr int PW = Lean<R>::PW;
     u.nq = (u.w + 3) >> 2;
     const int w4 = u.nq * 4;
-    u.pitch = w4 + ((pw - w4) & 15);  // pitch == patch (pair box) width (mod 16): conflict-free b128 reads across patch rows
-    if (!strict && (long)u.pitch * u.h > Lean<R>::kCap && (long)w4 * u.h <= Lean<R>::kCap) u.pitch = w4;
+    u.pitch = w4 + ((PW - w4) & 15);  // pitch == patch width (mod 16): conflict-free b128 reads across patch rows
+    if ((long)u.pitch * u.h > Lean<R>::kCap && (long)w4 * u.h <= Lean<R>::kCap) u.pitch = w4;
     if ((long)u.pitch * u.h > Lean<R>::kCap || u.w > 64) return false;
     // a multiple of 8 items, so that they split evenly over the 8 waves (every wave issues the same number of loads: no
     // branches around loads, exact wait counts)
@@ -206,16 +181,8 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
             hx1[h] = max(gx1[0], gx1[1]); hy1[h] = max(gy1[0], gy1[1]);
         }
         const bool all_in = __all(c.inside);
-        // pairs (round 6): lanes 2k, 2k + 1 hold horizontally adjacent cells; a cell without a patch pairs with anything
-        bool pairs_ok = false;
-        if constexpr (PairBox<R>::kOn) {
-            const int pX0 = __builtin_amdgcn_update_dpp(0, c.X0, 0xB1, 0xf, 0xf, false), pY0 = __builtin_amdgcn_update_dpp(0, c.Y0, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
-            const int dx = c.X0 - pX0, dy = c.Y0 - pY0;
-            pairs_ok = __all((c.X0 == kFar) | (pX0 == kFar) |
-                             ((dx <= PairBox<R>::BW - PW) & (-dx <= PairBox<R>::BW - PW) & (dy <= PairBox<R>::BH - PW) & (-dy <= PairBox<R>::BH - PW)));
-        }
         if (lane == 0) {
-            auto region = [&](int bx0, int by0, int bx1, int by1, RowPlan &u, int pw = Lean<R>::PW, bool strict = false) {
+            auto region = [&](int bx0, int by0, int bx1, int by1, RowPlan &u) {
                 // Border tiles: the region starts on a multiple of 4 pixels, so that a quad never straddles the image's left
                 // edge (a quad hanging over the right edge reads on into the next row, or past the tensor where the buffer
                 // returns zeros, and is masked per pixel).  Interior tiles: the same alignment makes the quads 16-byte
@@ -232,20 +199,12 @@ __device__ __forceinline__ void plan_tiles(const LcParams &p, unsigned wid0, uns
                 u.w = max(bx1 - u.x0, 0);
                 u.h = max(by1 - by0, 0);
                 if (u.w == 0 || u.h == 0) { u.x0 = 0; u.y0 = 0; u.w = 0; u.h = 0; }  // no window touches the image
-                return region_fits<R>(u, pw, strict);
+                return region_fits<R>(u);
             };
             RowPlan ua, ub;
             const bool border_ok = true;
             int flags = all_in ? kPlanInterior : 0;
-            // paired D-stage: only with its own conflict-free pitch (a pair's box rows are BW apart), and with a row of slack behind the
-            // region (a box may hang one row / three columns over the region's far corner: those reads must stay inside the stage)
-            bool full = false;
-            if (pairs_ok) {
-                full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua, PairBox<R>::BW, true) &&
-                       (long)ua.pitch * (ua.h + 1) + 4 <= Lean<R>::kCap;
-                if (full) flags |= kPlanPairs;
-            }
-            if (!full) full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
+            const bool full = region(min(hx0[0], hx0[1]), min(hy0[0], hy0[1]), max(hx1[0], hx1[1]), max(hy1[0], hy1[1]), ua) && border_ok;
             ub = ua;
             if (!full) {
                 const bool fa = region(hx0[0], hy0[0], hx1[0], hy1[0], ua), fb = region(hx0[1], hy0[1], hx1[1], hy1[1], ub);
@@ -319,12 +278,7 @@ struct DivPW {
 // falls back to vmcnt(0) and the cell set-up ends up waiting for the stage loads issued after it.
 // HALVES: the tile is staged as two 4 x 8-cell halves, one after the other (region uA for cells 0-31 = round 0, uB for cells
 // 32-63 = round 1); otherwise uA serves both rounds.
-// PAIR (round 6): the D-stage runs on pairs of horizontally adjacent cells (plan flag kPlanPairs; never with HALVES): a lane owns box
-// positions s + 16 t of ONE pair (wave w, lane group g -> pair 4 w + g = cells 8 w + 2 g, 8 w + 2 g + 1), every staged pixel it reads
-// is multiplied into both cells' sums by one v_pk_fma_f32 per channel (the two halves of the packed FMA are exact fmaf's, the channel
-// order is unchanged: results stay bit-identical to the single-cell D-stage).  LDS reads of staged pixels per tile: NPB instead of
-// 2 NP passes (r = 4: 9 instead of 14; r = 2: 4 instead of 6).
-template <int R, int NCH, bool CHECK, bool HALVES, typename FT, bool PAIR = false>
+template <int R, int NCH, bool CHECK, bool HALVES, typename FT>
 __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem, const RowPlan &uA, const RowPlan &uB, int b, int row0, int col0,
                                           int tid, int lane, int wave) {
     constexpr int ROUNDS = 2;
@@ -333,20 +287,13 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
     constexpr bool kTabIn = Lean<R>::kTabInStage;
     constexpr int PW = 2 * R + 2, P = PW * PW, NP = (P + 15) / 16;
     constexpr int D = 2 * R + 1, K = D * D;
-    static_assert(!(PAIR && HALVES), "pairs run on whole-tile regions");
-    static_assert(!PAIR || PairBox<R>::kOn, "pair box");
-    constexpr int BW = PairBox<R>::BW, BH = PairBox<R>::BH, PB = PairBox<R>::PB, NPB = PairBox<R>::NPB;
-    constexpr int NC = 64, DS = PAIR ? PairBox<R>::DSB : P + 1, TS = 2 * D + 1;   // (both D strides are odd)
-    constexpr int kMaxOff = PairBox<R>::kMaxOff;
-    constexpr int DROW = PAIR ? BW : PW;                              // row pitch of a cell's sums in the D buffer
+    constexpr int NC = 64, DS = P + 1, TS = 2 * D + 1;
     // Round 5: the epilogue's lanes 0-31 hold cells c and c + 32 (lane -> cell so that a wave stores whole grid-row segments), whose D
     // and table rows start 32 DS / 32 TS dwords apart = on the same bank: every epilogue read was a 2-way conflict.  Rows of cells
     // 32-63 are skewed by 16 dwords.
     constexpr int kSkew = 16;
     constexpr bool F0CH = Lean<R>::kF0Chunk;       // the f0 block goes through LDS one 16-channel chunk at a time
     constexpr int CS = (F0CH ? kChunk : C) + 4;
-    constexpr int CSP = 2 * C + 4;                 // PAIR: f0 rows are [pair][channel][2 cells] (+ 4: a wave's four pair rows on different banks)
-    static_assert(!PAIR || !F0CH, "the paired D-stage keeps the whole f0 block in LDS");
     static_assert((NC * DS + kSkew) * 4 <= kStageBytes, "D buffer must fit in the stage it aliases");
 
     float4 *s4 = reinterpret_cast<float4 *>(smem);
@@ -413,28 +360,6 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         }
     };
     auto f0_commit = [&]() {
-        if (PAIR) {
-            // [pair][channel][cell of the pair]: the lane's four consecutive cells are two pairs -> two 8-byte stores.  Pair rows of
-            // 2 C + 4 floats: the 16 (tile row, column quad, half) combinations of a store pass land on 8 distinct 8-bank groups, the
-            // lane's channel on the low banks inside one (2-way: the floor for 64 lanes x 8 bytes)
-            if (f0_lane) {
-#pragma unroll
-                for (int l = 0; l < NF0L; ++l) {
-                    const int ch = wave * NF0 + 4 * l + fk;
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const int fc = 4 * fqd + e;
-                        const int fcell = ((fc >> 3) << 5) | (fr << 3) | (fc & 7);
-                        const bool rok = row0 + fr < G;
-                        float2 v;
-                        v.x = (rok & (col0 + fc < G)) ? f0q[l][e] : 0.f;
-                        v.y = (rok & (col0 + fc + 1 < G)) ? f0q[l][e + 1] : 0.f;
-                        *reinterpret_cast<float2 *>(f0s + (fcell >> 1) * CSP + 2 * ch) = v;
-                    }
-                }
-            }
-            return;
-        }
         if (f0_lane) {
 #pragma unroll
             for (int l = 0; l < NF0L; ++l) {
@@ -514,23 +439,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 #ifndef GFN_LEAN_APK
 #define GFN_LEAN_APK 0
 #endif
-    constexpr bool kApk = GFN_LEAN_APK != 0 && !PAIR;
-    unsigned apk[PAIR ? 1 : ROUNDS][PAIR ? NPB : (kApk ? (NP + 1) / 2 : NP)];
-    const int pr = wave * 4 + g;  // PAIR: the lane's pair (cells 2 pr, 2 pr + 1)
-    auto pair_addressing = [&]() {
-        const int xa = cellX0[2 * pr], xb = cellX0[2 * pr + 1], ya = cellY0[2 * pr], yb = cellY0[2 * pr + 1];
-        // box origin: the minimum of the two patch origins (a cell without a patch -- kFar -- leaves it to its partner)
-        const int bx = min(xa, xb), by = min(ya, yb);
-        const int base = bx != kFar ? (by - uA.y0) * uA.pitch + (bx - uA.x0) : 0;
-#pragma unroll
-        for (int t = 0; t < NPB; ++t) {
-            const int pp = s16 + 16 * t;
-            const int yy = DivPW<BW>::div(pp), xx = pp - yy * BW;
-            int slot = base + yy * uA.pitch + xx;   // box positions no patch covers may lie past the region: inside the stage (plan), unused
-            if (16 * t + 15 >= PB) slot = pp < PB ? slot : 0;
-            apk[0][t] = (unsigned)(slot * kSlotV4) * 16u;
-        }
-    };
+    constexpr bool kApk = GFN_LEAN_APK != 0;
+    unsigned apk[ROUNDS][kApk ? (NP + 1) / 2 : NP];
     auto addressing = [&](int rd, int X0, int Y0) {
         const RowPlan &u = (HALVES && rd == 1) ? uB : uA;
         // cells without a patch (off the grid, flagged, empty) read slot 0 onwards: valid memory, result unused
@@ -579,21 +489,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
     }
 
-    static_assert(!PAIR || !kFlowAll, "pair addressing reads the cell arrays");
-    if (PAIR) {
-        pair_addressing();
-    } else if (!kFlowAll) {
+    if (!kFlowAll) {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) addressing(rd, cellX0[rd * 32 + cr], cellY0[rd * 32 + cr]);
     }
-    float acc[PAIR ? 1 : ROUNDS][PAIR ? 1 : NP];
-    f32x2 acc2[PAIR ? NPB : 1];
+    float acc[ROUNDS][NP];
 #pragma unroll
-    for (int rd = 0; rd < (PAIR ? 1 : ROUNDS); ++rd)
+    for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-        for (int t = 0; t < (PAIR ? 1 : NP); ++t) acc[rd][t] = 0.f;
-#pragma unroll
-    for (int t = 0; t < (PAIR ? NPB : 1); ++t) acc2[t] = f32x2{0.f, 0.f};
+        for (int t = 0; t < NP; ++t) acc[rd][t] = 0.f;
     STAMP(5);
 
     // ---- main loop: 16 channels at a time (per half when the tile is staged in halves) ------------------------------------
@@ -609,59 +513,15 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const RowPlan &un = (HALVES && nhalf == 1) ? uB : uA;
         const QuadLane &qn = (HALVES && nhalf == 1) ? qlB : qlA;
 #pragma unroll
-        for (int rd = 0; rd < (PAIR ? 1 : ROUNDS); ++rd)
+        for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-            for (int h = 0; h < (PAIR ? NPB : (kApk ? (NP + 1) / 2 : NP)); ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the (packed) addresses as they are: no recomputation per chunk
+            for (int h = 0; h < (kApk ? (NP + 1) / 2 : NP); ++h) asm volatile("" : "+v"(apk[rd][h]));  // keep the (packed) addresses as they are: no recomputation per chunk
         if (more && !ABL(p, 1)) {  // next step's loads: in flight across this D-stage
             quad_issue<PRE, CHECK, FT, kSlotV4, (R >= 3)>(pre, f1r, next_off, H, W, un, wave, lane, qn, 0);
             if (F0CH) f0_issue(nch * kChunk);
         }
-        if constexpr (PAIR) {
-            // quarter-steps of PQ channels: f2[k] = {f0 of cell A, f0 of cell B} of channel c0 + PQ q + k, a position's PQ channels come
-            // in PQ / 4 16-byte reads and go into PQ packed FMAs.  op_sel / op_sel_hi broadcast the pixel value (low or high half of its
-            // register pair) to both halves of the product: lo = fmaf(fA, v, accA), hi = fmaf(fB, v, accB), each exact.
-            // (PQ = 8 -- 16 registers of f0 pairs, 8 of pixels per position in flight -- spilled ~50 registers in the D-stage at 128.)
-#ifndef GFN_LEAN_PQ
-#define GFN_LEAN_PQ 4
-#endif
-            constexpr int PQ = GFN_LEAN_PQ;
-            static_assert(PQ == 4 || PQ == 8, "channels per sub-step");
 #pragma unroll
-            for (int hf = 0; hf < kChunk / PQ; ++hf) {
-                if (ABL(p, 2)) continue;
-                f32x2 f2[PQ];
-                {
-                    const f32x4 *fq = reinterpret_cast<const f32x4 *>(f0s + pr * CSP + 2 * (c0 + PQ * hf));
-#pragma unroll
-                    for (int k = 0; k < PQ / 2; ++k) {
-                        const f32x4 a = fq[k];
-                        f2[2 * k] = __builtin_shufflevector(a, a, 0, 1);
-                        f2[2 * k + 1] = __builtin_shufflevector(a, a, 2, 3);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NPB; ++t) {
-                    const f32x4 *q = reinterpret_cast<const f32x4 *>(smem + apk[0][t]) + (PQ / 4) * hf;
-                    f32x2 a = acc2[t];
-#define GFN_PKLO(F, V) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(a) : "v"(F), "v"(V))
-#define GFN_PKHI(F, V) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(F), "v"(V))
-#pragma unroll
-                    for (int k = 0; k < PQ / 4; ++k) {
-                        const f32x4 v = q[k];
-                        const f32x2 p0 = __builtin_shufflevector(v, v, 0, 1), p1 = __builtin_shufflevector(v, v, 2, 3);
-                        GFN_PKLO(f2[4 * k], p0); GFN_PKHI(f2[4 * k + 1], p0); GFN_PKLO(f2[4 * k + 2], p1); GFN_PKHI(f2[4 * k + 3], p1);
-                    }
-#undef GFN_PKLO
-#undef GFN_PKHI
-                    acc2[t] = a;
-                }
-                // one sub-step at a time: merged, the scheduler hoists every sub-step's reads (4 x NPB x 4 registers) to the front and the
-                // staging prefetch registers go to scratch behind vmcnt(0) waits
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int rd = 0; rd < (PAIR ? 0 : ROUNDS); ++rd) {
+        for (int rd = 0; rd < ROUNDS; ++rd) {
             if (HALVES && rd != half) continue;
             if (ABL(p, 2)) continue;
             float f[kChunk];
@@ -686,11 +546,9 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rd = 0; rd < (PAIR ? 0 : ROUNDS); ++rd)
+        for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
             for (int t = 0; t < NP; ++t) asm volatile("" : "+v"(acc[rd][t]));  // pins the FMAs above this point
-#pragma unroll
-        for (int t = 0; t < (PAIR ? NPB : 0); ++t) asm volatile("" : "+v"(acc2[t]));
         STAMP(st == 0 ? 6 : 9);
         if (more) {
             __syncthreads();  // everyone is done reading this step's pixels
@@ -716,27 +574,8 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         if (!ABL(p, 32)) tab_bad = fill_table(cellNx[lane], cellNy[lane], cellX0[lane], cellY0[lane]);
         if (tab_bad && atomicOr(&cellFlag[lane], kCellSlow) == 0) atomicAdd(&hdr[4], 1);  // rare
     }
-    if (PAIR) {
-        // A cell's sums go to its D-buffer row shifted so that its PATCH (not its pair's box) starts at offset kMaxOff: the epilogue's
-        // lanes (one per cell) then read the same offsets of rows an odd stride apart -- conflict-free like the single-cell layout.
-        // (With the box stored as it is, every cell's patch started at its own offset 0..16 and the epilogue's reads collided: LDS bank
-        // conflicts 113 -> 217 clocks per wave, all of the paired D-stage's gain.)
-        const int ca = 2 * pr, sk = (ca >> 5) * kSkew;   // both cells of a pair lie in the same half
-        const int xa = cellX0[ca], xb = cellX0[ca + 1], ya = cellY0[ca], yb = cellY0[ca + 1];
-        const int bx = min(xa, xb), by = min(ya, yb);
-        const int sha = kMaxOff - (xa != kFar ? (ya - by) * BW + (xa - bx) : 0), shb = kMaxOff - (xb != kFar ? (yb - by) * BW + (xb - bx) : 0);
-        float *da = dbuf + ca * DS + sk + sha, *db = dbuf + (ca + 1) * DS + sk + shb;
 #pragma unroll
-        for (int t = 0; t < NPB; ++t) {
-            const int pp = s16 + 16 * t;
-            if (pp < PB && !ABL(p, 16)) {
-                da[pp] = acc2[t][0];
-                db[pp] = acc2[t][1];
-            }
-        }
-    }
-#pragma unroll
-    for (int rd = 0; rd < (PAIR ? 0 : ROUNDS); ++rd) {
+    for (int rd = 0; rd < ROUNDS; ++rd) {
         const int cell = rd * 32 + cr;
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
@@ -755,7 +594,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
         const int flag = cellFlag[cell];
         if ((gi < G) & (gj < G) & !(flag & kCellSlow) & !ABL(p, 8)) {
             const bool empty = (flag & kCellEmpty) != 0;
-            const float *dc = dbuf + cell * DS + (ec >> 3) * kSkew + (PAIR ? kMaxOff : 0);
+            const float *dc = dbuf + cell * DS + (ec >> 3) * kSkew;
             const float *tc = tab + cell * TS + (ec >> 3) * kSkew;
             const unsigned goff = (unsigned)(gi * G + gj) * 4u;
             const rsrc_t outr = make_rsrc(p.out + (size_t)b * p.out_bs, (unsigned)K * GG4);
@@ -771,10 +610,10 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
                     // weights), every tap is then two instructions
                     const float wy1 = tc[D + ky];
                     const float wy1s = wy1 * p.inv_sqrt_c, wy0s = (1.f - wy1) * p.inv_sqrt_c;
-                    const float *d = dc + ky * DROW;
+                    const float *d = dc + ky * PW;
                     float m[PW];
 #pragma unroll
-                    for (int x = 0; x < PW; ++x) m[x] = fmaf(d[DROW + x], wy1s, d[x] * wy0s);
+                    for (int x = 0; x < PW; ++x) m[x] = fmaf(d[PW + x], wy1s, d[x] * wy0s);
 #pragma unroll
                     for (int kx = 0; kx < D; ++kx) {
                         const float val = fmaf(m[kx + 1], wx1[kx], m[kx] * wx0[kx]);
@@ -839,8 +678,7 @@ __device__ __forceinline__ void lean_tile(const LcParams &p, unsigned char *smem
 template <int R>
 constexpr int lean_workers() { return (GFN_LEAN_INLINE_WORKERS && R >= 3) ? 256 : 0; }  // a multiple of 8: the XCD of a tile's workgroup does not change
 
-// one 4 x 16-cell tile `wid` from its plan record: the body of the tile kernel (also the fall-back of the 8 x 16-cell kernel of
-// local_corr_big.h for tile pairs that do not take its path)
+// one 4 x 16-cell tile `wid` from its plan record: the body of the tile kernel
 template <int R, int NCH, typename FT>
 __device__ __forceinline__ void lean_small_tile(const LcParams &p, unsigned char *smem, unsigned wid, int tid, int lane, int wave) {
     // the tile's plan through the scalar cache: a vector load of it would queue behind whatever the CU's other workgroups
@@ -868,17 +706,10 @@ __device__ __forceinline__ void lean_small_tile(const LcParams &p, unsigned char
     }
     const int b = pg[1], row0 = pg[2] & 0xffff, col0 = pg[2] >> 16;
     const bool interior = (flags & kPlanInterior) != 0;
-#ifdef GFN_LEAN_ANALYZE  // tools/isa_phases.py: only the interior whole-tile variant, so that the hot path is straight-line code in the dump
+#ifdef GFN_LEAN_ANALYZE  // ISA reading aid (tools/dump_isa.py): only the interior whole-tile variant, so that the hot path is straight-line code in the dump
     lean_tile<R, NCH, false, false, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
     return;
 #endif
-    if constexpr (PairBox<R>::kOn && !Lean<R>::kF0Chunk) {
-        if (flags & kPlanPairs) {
-            if (interior) lean_tile<R, NCH, false, false, FT, true>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
-            else lean_tile<R, NCH, true, false, FT, true>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
-            return;
-        }
-    }
     if (flags & kPlanHalves) {
         if (interior) lean_tile<R, NCH, false, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
         else lean_tile<R, NCH, true, true, FT>(p, smem, uA, uB, b, row0, col0, tid, lane, wave);
@@ -900,13 +731,6 @@ __global__ __launch_bounds__(kThreads, Lean<R>::kMinWaves) void local_corr_tile2
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef GFN_LEAN_STAGGER  // experiment (round 6): the second workgroup of every CU starts GFN_LEAN_STAGGER x ~8 k cycles late (first dispatch round only)
-    {
-        const unsigned tb = blockIdx.x - kLeanWorkers;
-        if (tb < 512u && ((tb >> 8) & 1u))
-            for (int i = 0; i < GFN_LEAN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const unsigned wid = gfn::xcd_remap(blockIdx.x - kLeanWorkers, gridDim.x - kLeanWorkers);
     lean_small_tile<R, NCH, FT>(p, smem, wid, tid, lane, wave);
 }

@@ -13,7 +13,6 @@ struct RowPlan {  // block-uniform (scalars)
 // ---- buffer addressing --------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4 make_i32x4(int a, int b, int c, int d) { i32x4 v = {a, b, c, d}; return v; }
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {

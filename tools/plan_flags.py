@@ -41,5 +41,5 @@ for (c, hs, G, r) in [(32, 112, 64, 4), (32, 140, 80, 4), (16, 224, 128, 2), (16
     fl = plan[:, 3]
     w, h = plan[:, 2] & 0xffff, plan[:, 2] >> 16
     pitch = plan[:, 7] & 0xff
-    print(f"{kind} c{c} {hs}^2 G{G} r{r}: tiles {tiles}; pairs {np.mean((fl & 8) != 0):.3f}, halves {np.mean((fl & 4) != 0):.3f}, second {np.mean((fl & 2) != 0):.4f}, "
+    print(f"{kind} c{c} {hs}^2 G{G} r{r}: tiles {tiles}; halves {np.mean((fl & 4) != 0):.3f}, second {np.mean((fl & 2) != 0):.4f}, "
           f"interior {np.mean((fl & 1) != 0):.3f}; region w x h median {int(np.median(w))} x {int(np.median(h))} (max {w.max()} x {h.max()}), pitch median {int(np.median(pitch))}", flush=True)
