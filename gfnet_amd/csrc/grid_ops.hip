@@ -18,21 +18,15 @@ namespace {
 
 using namespace gfn_ri;
 
-template <typename FT, bool KEEP, bool PAIRED>
+template <typename FT, bool KEEP>
 __global__ __launch_bounds__(256) void refiner_input_kernel(RiArgs q, unsigned q_blocks, int banded) {
     if (banded) {  // 1-D grid, XCD-banded order (refiner_input.h)
         int b;
         unsigned x;
-        if (ri_banded(blockIdx.x, q_blocks, q.Bh, b, x)) refiner_input_item<FT, KEEP, PAIRED>(q, b, x * 256u + threadIdx.x);
+        if (ri_banded(blockIdx.x, q_blocks, q.Bh, b, x)) refiner_input_cell<FT, KEEP>(q, b, x * 256u + threadIdx.x);
         return;
     }
-    refiner_input_item<FT, KEEP, PAIRED>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * 256u + threadIdx.x);
-}
-
-template <typename FT, bool KEEP>
-void launch_refiner_input(bool paired, dim3 grid, hipStream_t s, const RiArgs &q, unsigned q_blocks, int banded) {
-    if (paired) hipLaunchKernelGGL((refiner_input_kernel<FT, KEEP, true>), grid, dim3(256), 0, s, q, q_blocks, banded);
-    else hipLaunchKernelGGL((refiner_input_kernel<FT, KEEP, false>), grid, dim3(256), 0, s, q, q_blocks, banded);
+    refiner_input_cell<FT, KEEP>(q, ri_direction(q.B, q.Bh, blockIdx.y), blockIdx.x * 256u + threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float *__restrict__ in, const float *__restrict__ grid,
@@ -261,9 +255,7 @@ GFN_EXPORT int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtyp
         return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: bad size");
     if (B == 0) return GFN_OK;
     if (B > 65535 || (long)G * G >= (1L << 31)) return gfn::fail(GFN_ERR_INVALID_ARG, "refiner_input: batch > 65535 or grid too large");
-    // two cells per thread where the shape allows it (refiner_input.h, round 6) and the 8-byte row segments are aligned
-    const bool paired = gfn_ri::ri_paired(B, G, Ws) && (((uintptr_t)flow | (uintptr_t)d) & 7) == 0 && (d_bs & 1) == 0;
-    const unsigned q_blocks = (unsigned)(((paired ? (long)G * G / 2 : (long)G * G) + 255) / 256);
+    const unsigned q_blocks = (unsigned)(((long)G * G + 255) / 256);
     RiArgs q;
     q.fa = f0; q.fb = f1; q.flow = flow; q.dw = disp_w; q.db = disp_b; q.d = d; q.d_bs = (long)d_bs;
     q.B = B; q.Bh = (symmetric & 1) ? B / 2 : B; q.C = C; q.Hs = Hs; q.Ws = Ws; q.G = G; q.Dd = disp_dim; q.disp_scale = disp_scale;
@@ -271,11 +263,11 @@ GFN_EXPORT int gfn_refiner_input_fwd_dt(const void *f0, const void *f1, int dtyp
     const int banded = gfn_ri::ri_bands(q.B, q.Bh, q_blocks) ? 1 : 0;
     const dim3 grid = banded ? dim3(gfn_ri::ri_banded_blocks(B, q_blocks)) : dim3(q_blocks, (unsigned)B);
     if (dtype == GFN_F16) {
-        if (keep) launch_refiner_input<_Float16, true>(paired, grid, (hipStream_t)stream, q, q_blocks, banded);
-        else launch_refiner_input<_Float16, false>(paired, grid, (hipStream_t)stream, q, q_blocks, banded);
+        if (keep) hipLaunchKernelGGL((refiner_input_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream, q, q_blocks, banded);
+        else hipLaunchKernelGGL((refiner_input_kernel<_Float16, false>), grid, dim3(256), 0, (hipStream_t)stream, q, q_blocks, banded);
     } else {
-        if (keep) launch_refiner_input<float, true>(paired, grid, (hipStream_t)stream, q, q_blocks, banded);
-        else launch_refiner_input<float, false>(paired, grid, (hipStream_t)stream, q, q_blocks, banded);
+        if (keep) hipLaunchKernelGGL((refiner_input_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, q, q_blocks, banded);
+        else hipLaunchKernelGGL((refiner_input_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, q, q_blocks, banded);
     }
     return gfn::check_launch("refiner_input_kernel");
 }

@@ -1171,19 +1171,13 @@ namespace {
 template <int R, typename FT>
 int launch_ri_plan(const gfn_ri::RiArgs &q, LcParams p, hipStream_t s, bool keep) {
     lean_window_params<R>(p);
-    const bool paired = gfn_ri::ri_paired(q.B, q.G, q.Ws) && (((uintptr_t)q.flow | (uintptr_t)q.d) & 7) == 0 && (q.d_bs & 1) == 0;  // two cells per thread
-    const unsigned q_blocks = (unsigned)(((paired ? (long)q.G * q.G / 2 : (long)q.G * q.G) + 255) / 256);
+    const unsigned q_blocks = (unsigned)(((long)q.G * q.G + 255) / 256);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     const unsigned p_blocks = (tiles + 4 * kPlanPerWave - 1) / (4 * kPlanPerWave);
     const int banded = gfn_ri::ri_bands(q.B, q.Bh, q_blocks) ? 1 : 0;  // symmetric batches: XCD-banded order of the refiner-input blocks
     const dim3 grid = banded ? dim3(gfn_ri::ri_banded_blocks(q.B, q_blocks) + p_blocks * (unsigned)q.B) : dim3(q_blocks + p_blocks, (unsigned)q.B);
-    if (paired) {
-        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true, true>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
-        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false, true>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
-    } else {
-        if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true, false>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
-        else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false, false>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
-    }
+    if (keep) hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, true>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
+    else hipLaunchKernelGGL((refiner_input_plan_kernel<R, FT, false>), grid, dim3(256), 0, s, q, p, q_blocks, p_blocks, banded);
     return gfn::check_launch("refiner_input_plan_kernel");
 }
 }  // namespace

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void local_corr_plan_kernel(LcParams p) {
 // The refiner-input kernel and the plan of the local correlation that follows it in ConvRefiner.forward (network.py:537-555) in
 // ONE launch: blockIdx.x < q_blocks are refiner-input blocks of direction blockIdx.y, the rest plan that direction's tiles
 // (16 per block).  Both only read the flow; the plan's ~8 us and a kernel boundary disappear from the local-correlation call.
-template <int R, typename FT, bool KEEP, bool PAIRED>
+template <int R, typename FT, bool KEEP>
 __global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs q, LcParams p, unsigned q_blocks, unsigned p_blocks, int banded) {
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
     if (banded) {  // 1-D grid: the refiner-input blocks of all directions in XCD-banded order (refiner_input.h), the plan blocks behind them
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs 
         if (blockIdx.x < nq) {
             int b;
             unsigned x;
-            if (gfn_ri::ri_banded(blockIdx.x, q_blocks, q.Bh, b, x)) gfn_ri::refiner_input_item<FT, KEEP, PAIRED>(q, b, x * 256u + threadIdx.x);
+            if (gfn_ri::ri_banded(blockIdx.x, q_blocks, q.Bh, b, x)) gfn_ri::refiner_input_cell<FT, KEEP>(q, b, x * 256u + threadIdx.x);
             return;
         }
         const unsigned pid = blockIdx.x - nq, pb = pid / p_blocks, px = pid - pb * p_blocks;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void refiner_input_plan_kernel(gfn_ri::RiArgs 
     }
     const int b = gfn_ri::ri_direction(q.B, q.Bh, blockIdx.y);
     if (blockIdx.x < q_blocks) {
-        gfn_ri::refiner_input_item<FT, KEEP, PAIRED>(q, b, blockIdx.x * 256u + threadIdx.x);
+        gfn_ri::refiner_input_cell<FT, KEEP>(q, b, blockIdx.x * 256u + threadIdx.x);
         return;
     }
     const unsigned first = (unsigned)b * tiles + ((blockIdx.x - q_blocks) * 4u + (threadIdx.x >> 6)) * kPlanPerWave;

@@ -74,7 +74,6 @@ __device__ __forceinline__ BilinC bilin_clamped(float gx, float gy, int W, int H
 struct BilinP {
     unsigned o[2];
     float w[4];
-    int ox;          // column of the fetched pair (refiner_input_cell2)
 };
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -86,7 +85,6 @@ __device__ __forceinline__ BilinP bilin_pairs(float gx, float gy, int W, int H) 
     const float l0 = (s.xa & (s.x0 == ox)) ? 1.f : 0.f, l1 = (s.xb & (s.x0 + 1 == ox)) ? 1.f : 0.f;      // left stands for x0 / x0+1
     const float r0 = (s.xa & (s.x0 == ox + 1)) ? 1.f : 0.f, r1 = (s.xb & (s.x0 + 1 == ox + 1)) ? 1.f : 0.f;  // right stands for x0 / x0+1
     const float ta = s.ya ? 1.f : 0.f, tb = s.yb ? 1.f : 0.f;
-    c.ox = ox;
     c.o[0] = (unsigned)((s.ya ? s.y0 : 0) * W + ox);
     c.o[1] = (unsigned)((s.yb ? s.y0 + 1 : 0) * W + ox);
     // exactly one of (l0, l1) and one of (r0, r1) can be 1, so each product below is w or 0 -- no rounding added
@@ -225,136 +223,6 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
     // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
     const float dx = disp_scale * (fx - cx), dy = disp_scale * (fy - cy);
     for (int k = 0; k < Dd; ++k) __builtin_nontemporal_store(dw[k * 2 + 0] * dx + dw[k * 2 + 1] * dy + db[k], o + (size_t)(2 * C + k) * GG + cell);
-}
-
-
-// ---- round 6: TWO horizontally adjacent cells per thread -----------------------------------------------------------------------
-// The kernel is bound by the CU's vector-memory ISSUE path, not by bytes (round 1: halving the gather instructions gave 23 %): a
-// wave-level load or store costs its ~16 clocks of the texture-address path whether a lane moves 4, 8 or 16 bytes.  With cells
-// (i, 2m) and (i, 2m + 1) in one thread
-//   * grid_feature: the two cells sit on the same grid row (same map rows) and their sample columns are <= 2 pixels apart when the
-//     map is at most twice the grid (every GFNet scale: 1.75; scale 16: 1), so ONE 16-byte gather per map row and channel
-//     (4-byte aligned, the quad starting at the left cell's pair, clamped to the row) holds both cells' pixel pairs: half the
-//     gather instructions, every lane moving 16 bytes; the pairs are picked out of the quad with selects (values, not weights: a
-//     pixel that is not a corner must not reach the sum even as 0 * inf);
-//   * x_hat follows the flow (the two cells' rows differ for 45 % of the pairs under a 15-degree rotation): two pair gathers as before;
-//   * all 2 C + Dd planes are written as 8-byte row segments: half the store instructions.
-// Per 128 cells a wave issues 8 C + 16 C + (2 C + Dd) = 232 vector-memory instructions at C = Dd = 8 instead of 2 x (16 C + 2 C + Dd)
-// = 304... per 64-lane wave: see DESIGN.md section 4 for the counted figures.  Sums and weights are those of refiner_input_cell:
-// results are bit-identical.
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-struct __attribute__((packed, aligned(2))) h16x4u { _Float16 x, y, z, w; };
-__device__ __forceinline__ f32x4u ld_quad(const float *q) { return *reinterpret_cast<const f32x4u *>(q); }
-__device__ __forceinline__ f32x4u ld_quad(const _Float16 *q) {
-    const h16x4u v = *reinterpret_cast<const h16x4u *>(q);
-    f32x4u o;
-    o.x = (float)v.x; o.y = (float)v.y; o.z = (float)v.z; o.w = (float)v.w;
-    return o;
-}
-typedef float f32x2a __attribute__((ext_vector_type(2)));
-
-// host side: the paired form needs an even grid (pairs do not straddle grid rows), a map at most twice the grid, rows of >= 4 pixels
-#ifndef GFN_RI_PAIRED
-#define GFN_RI_PAIRED 1   // 0: A/B builds with one cell per thread everywhere
-#endif
-// ... and enough pairs to fill the chip twice over with 256-thread blocks: below that the halved thread count costs more than the saved
-// instructions (64 directions: G = 32 stays on one cell per thread, 32.5 vs 34.5 us; G = 64 is level; G >= 128 gains 5-12 %)
-inline bool ri_paired(int B, int G, int Ws) {
-    return GFN_RI_PAIRED != 0 && (G & 1) == 0 && Ws >= 4 && Ws <= 2 * G && (long)B * G * G / 2 >= 2L * 256 * 256;
-}
-
-template <typename FT, bool KEEP = false>
-__device__ __forceinline__ void refiner_input_cell2(const RiArgs &args, int b, unsigned item) {
-    const FT *__restrict__ fa = static_cast<const FT *>(args.fa);
-    const FT *__restrict__ fb = static_cast<const FT *>(args.fb);
-    const float *__restrict__ flow = args.flow, *__restrict__ dw = args.dw, *__restrict__ db = args.db;
-    float *__restrict__ d = args.d;
-    const long d_bs = args.d_bs;
-    const int Bh = args.Bh, C = args.C, Hs = args.Hs, Ws = args.Ws, G = args.G, Dd = args.Dd;
-    const float disp_scale = args.disp_scale;
-    const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
-    const unsigned plane = (unsigned)(Hs * Ws), GG = (unsigned)(G * G);
-    const unsigned cell = 2u * item;  // the left cell; G is even, so cell + 1 is its right neighbour in the same grid row
-    if (cell >= GG) return;
-    const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
-    const FT *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
-    const FT *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
-    const float cy = gfn::linspace_at(lo, hi, G, i);
-    const float cx0 = gfn::linspace_at(lo, hi, G, j), cx1 = gfn::linspace_at(lo, hi, G, j + 1);  // network.py:539-546
-    const float *fl = flow + (size_t)b * 2 * GG;
-    const f32x2a fx = *reinterpret_cast<const f32x2a *>(fl + cell), fy = *reinterpret_cast<const f32x2a *>(fl + GG + cell);
-    float *o = d + (size_t)b * d_bs;
-    const BilinP sa0 = bilin_pairs(cx0, cy, Ws, Hs), sa1 = bilin_pairs(cx1, cy, Ws, Hs);   // grid_feature   network.py:547
-    const BilinP sb0 = bilin_pairs(fx.x, fy.x, Ws, Hs), sb1 = bilin_pairs(fx.y, fy.y, Ws, Hs);  // x_hat     network.py:537
-    // the quad of a map row: starts at the left cell's pair, pulled back so that it ends inside the row.  Both cells share the rows
-    // (same cy), so sa0.o[e] - column = sa1.o[e] - column = the row's offset.
-    unsigned oq[2];
-    int off0, off1;
-    {
-        const int ox0 = sa0.ox, ox1 = sa1.ox;
-        const int xq = min(ox0, Ws - 4);
-        off0 = ox0 - xq;      // 0..2
-        off1 = ox1 - xq;      // 0..2 (ox1 - ox0 <= 2 because Ws <= 2 G)
-        oq[0] = sa0.o[0] - (unsigned)ox0 + (unsigned)xq;
-        oq[1] = sa0.o[1] - (unsigned)ox0 + (unsigned)xq;
-    }
-    auto pick = [](const f32x4u v, int off, float &l, float &r) {
-        l = off == 0 ? v.x : (off == 1 ? v.y : v.z);
-        r = off == 0 ? v.y : (off == 1 ? v.z : v.w);
-    };
-    constexpr int CG = 4;  // channels per group: 4 x 2 quads + 2 x 4 x 2 pairs = 64 registers of gathers in flight
-    for (int c0 = 0; c0 < C; c0 += CG) {
-        f32x4u va[CG][2];
-        f32x2u vb0[CG][2], vb1[CG][2];
-#pragma unroll
-        for (int k = 0; k < CG; ++k) {
-            const FT *qp = q + (size_t)min(c0 + k, C - 1) * plane, *sp = sm + (size_t)min(c0 + k, C - 1) * plane;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (!KEEP) va[k][e] = ld_quad(qp + oq[e]);
-                vb0[k][e] = ld_pair(sp + sb0.o[e]);
-                vb1[k][e] = ld_pair(sp + sb1.o[e]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CG; ++k) {
-            if (c0 + k < C) {
-                f32x2a ra = {0.f, 0.f}, rb = {0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (!KEEP) {
-                        float l, r;
-                        pick(va[k][e], off0, l, r);
-                        ra.x += l * sa0.w[2 * e];
-                        ra.x += r * sa0.w[2 * e + 1];
-                        pick(va[k][e], off1, l, r);
-                        ra.y += l * sa1.w[2 * e];
-                        ra.y += r * sa1.w[2 * e + 1];
-                    }
-                    rb.x += vb0[k][e].x * sb0.w[2 * e];
-                    rb.x += vb0[k][e].y * sb0.w[2 * e + 1];
-                    rb.y += vb1[k][e].x * sb1.w[2 * e];
-                    rb.y += vb1[k][e].y * sb1.w[2 * e + 1];
-                }
-                if (!KEEP) *reinterpret_cast<f32x2a *>(o + (size_t)(c0 + k) * GG + cell) = ra;  // read back at once as the local correlation's f0: stays cached
-                __builtin_nontemporal_store(rb, reinterpret_cast<f32x2a *>(o + (size_t)(C + c0 + k) * GG + cell));
-            }
-        }
-    }
-    // disp_emb(40/32 * scale_factor * (flow - im_A_coords))                                  network.py:548-549
-    const float dx0 = disp_scale * (fx.x - cx0), dy0 = disp_scale * (fy.x - cy), dx1 = disp_scale * (fx.y - cx1), dy1 = disp_scale * (fy.y - cy);
-    for (int k = 0; k < Dd; ++k) {
-        const float w0 = dw[k * 2 + 0], w1 = dw[k * 2 + 1], bk = db[k];
-        const f32x2a v = {w0 * dx0 + w1 * dy0 + bk, w0 * dx1 + w1 * dy1 + bk};
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x2a *>(o + (size_t)(2 * C + k) * GG + cell));
-    }
-}
-
-// the cell function of a launch: one cell or two per thread (PAIRED is the host's ri_paired(G, Ws))
-template <typename FT, bool KEEP, bool PAIRED>
-__device__ __forceinline__ void refiner_input_item(const RiArgs &args, int b, unsigned item) {
-    if constexpr (PAIRED) refiner_input_cell2<FT, KEEP>(args, b, item);
-    else refiner_input_cell<FT, KEEP>(args, b, item);
 }
 
 
