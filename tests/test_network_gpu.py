@@ -294,11 +294,15 @@ def test_pooled_streams_run_side_by_side():
 
     pool = parallel.concurrent_streams(3)
     assert len(pool) == 3 and len({s.cuda_stream for s in pool}) == 3
-    # the overlap itself is a diagnostic, not an assertion (a wall-time heuristic on a shared GPU): reported, and only a
-    # pool in which NO pair overlaps -- every member on one queue -- fails
-    ratios = {(i, j): parallel._overlap_ratio(pool[i], pool[j], 400_000) for i in range(3) for j in range(i + 1, 3)}
-    print("spin-pair time / spin-alone time per stream pair:", {k: round(v, 2) for k, v in ratios.items()})
-    assert min(ratios.values()) < 1.5, ratios
+    # a wall-time heuristic on a GPU that other processes may share, so each pair's verdict is the MEDIAN of three probes;
+    # at least two of the three pairs must overlap (evaluate() and bench.py rely on the three-way overlap -- a pool in which
+    # two members share a hardware queue, which the bench-time guard works around, must fail here)
+    import statistics
+
+    ratios = {(i, j): statistics.median(parallel._overlap_ratio(pool[i], pool[j], 400_000) for _ in range(3))
+              for i in range(3) for j in range(i + 1, 3)}
+    print("spin-pair time / spin-alone time per stream pair (median of 3):", {k: round(v, 2) for k, v in ratios.items()})
+    assert sum(v < 1.5 for v in ratios.values()) >= 2, ratios
     again = parallel.concurrent_streams(2)
     assert again[0] is pool[0] and again[1] is pool[1]
     import warnings

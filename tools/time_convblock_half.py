@@ -3,8 +3,12 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _abl = os.path.join(ROOT, "gfnet_amd", "csrc", "libgfnet_hip_ablate.so")
+_prod = os.path.join(ROOT, "gfnet_amd", "csrc", "libgfnet_hip.so")
 if os.path.exists(_abl) and "GFNET_HIP_LIB" not in os.environ:
+    if os.path.exists(_prod) and os.path.getmtime(_abl) < os.path.getmtime(_prod):  # never time a stale experiment build silently
+        sys.exit(f"{_abl} is older than {_prod}: rebuild it (python -m gfnet_amd.build --ablate) or set GFNET_HIP_LIB")
     os.environ["GFNET_HIP_LIB"] = _abl
+print("library:", os.environ.get("GFNET_HIP_LIB", _prod), flush=True)
 import torch
 sys.path.insert(0, ROOT)
 from gfnet_amd import ops
