@@ -156,7 +156,7 @@ struct RiArgs {
 // already in d from an earlier call with the same x and G -- the second refiner iteration at a scale (num_itr = 2,
 // model/network.py:257-268, calls the refiner again with a new flow): only x_hat and the displacement embedding are rewritten.
 template <typename FT, bool KEEP = false>
-__device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, unsigned cell) {
+__device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, unsigned cell) {  // cell: the thread's index inside the direction
     const FT *__restrict__ fa = static_cast<const FT *>(args.fa);
     const FT *__restrict__ fb = static_cast<const FT *>(args.fb);
     const float *__restrict__ flow = args.flow, *__restrict__ dw = args.dw, *__restrict__ db = args.db;
@@ -167,6 +167,18 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
     const float lo = (float)(-1 + 1.0 / G), hi = (float)(1 - 1.0 / G);
     const unsigned plane = (unsigned)(Hs * Ws), GG = (unsigned)(G * G);
     if (cell >= GG) return;
+#ifndef GFN_RI_WAVE2D
+#define GFN_RI_WAVE2D 1
+#endif
+    if (GFN_RI_WAVE2D && (G & 31) == 0) {
+        // Round 6: a wave's 64 cells are 2 grid rows x 32 columns instead of 1 x 64.  The x_hat gathers follow the flow: under the
+        // bench's homographies a 64-lane pair gather of a 1 x 64 wave touches 13.9 128-byte lines (rows drift with the rotation), of a
+        // 2 x 32 wave 11.3; the regular grid_feature gather goes from 4 to 5 lines, the stores stay two full lines per instruction
+        // (2 x 128 bytes).  A permutation of the cells inside a direction: results are unchanged.
+        const unsigned w = cell >> 6, l = cell & 63u, wpr = (unsigned)G >> 5;   // waves per row pair
+        const unsigned rp = w / wpr, cb = w - rp * wpr;
+        cell = (2u * rp + (l >> 5)) * (unsigned)G + cb * 32u + (l & 31u);
+    }
     const int i = (int)(cell / (unsigned)G), j = (int)(cell - (unsigned)i * (unsigned)G);
     const FT *q = (b < Bh ? fa + (size_t)b * C * plane : fb + (size_t)(b - Bh) * C * plane);  // query map
     const FT *sm = (b < Bh ? fb + (size_t)b * C * plane : fa + (size_t)(b - Bh) * C * plane); // support map
