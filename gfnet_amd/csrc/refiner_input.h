@@ -174,7 +174,8 @@ __device__ __forceinline__ void refiner_input_cell(const RiArgs &args, int b, un
         // Round 6: a wave's 64 cells are 2 grid rows x 32 columns instead of 1 x 64.  The x_hat gathers follow the flow: under the
         // bench's homographies a 64-lane pair gather of a 1 x 64 wave touches 13.9 128-byte lines (rows drift with the rotation), of a
         // 2 x 32 wave 11.3; the regular grid_feature gather goes from 4 to 5 lines, the stores stay two full lines per instruction
-        // (2 x 128 bytes).  A permutation of the cells inside a direction: results are unchanged.
+        // (2 x 128 bytes).  A permutation of the cells inside a direction: results are unchanged.  (4 x 16 waves for grids that are a
+        // multiple of 16 only -- G = 80, 48, 240 -- measured 0.5-0.9 % SLOWER: four rows of grid_feature gathers cost more than the x_hat gathers save.)
         const unsigned w = cell >> 6, l = cell & 63u, wpr = (unsigned)G >> 5;   // waves per row pair
         const unsigned rp = w / wpr, cb = w - rp * wpr;
         cell = (2u * rp + (l >> 5)) * (unsigned)G + cb * 32u + (l & 31u);

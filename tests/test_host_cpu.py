@@ -257,3 +257,29 @@ def test_refiner_keeps_the_flags_the_reference_stores_without_reading_them():
     assert list(plain.state_dict()) == list(flagged.state_dict())
     for (k, a), b in zip(plain.state_dict().items(), flagged.state_dict().values()):
         assert torch.equal(a, b), k
+
+
+def test_refiner_input_wave_mapping_is_a_permutation_of_the_cells():
+    """csrc/refiner_input.h (round 6): thread index -> cell so that a wave covers 2 grid rows x 32 columns.  The kernel's integer
+    expressions restated: every cell of a direction is visited exactly once, a wave's 64 threads form the block, and grids that are not
+    a multiple of 32 keep the linear order."""
+    import numpy as np
+
+    def remap(cell, G):
+        if G % 32:
+            return cell
+        w, lane, wpr = cell >> 6, cell & 63, G >> 5
+        rp, cb = w // wpr, w % wpr
+        return (2 * rp + (lane >> 5)) * G + cb * 32 + (lane & 31)
+
+    for G in (16, 32, 48, 64, 80, 96, 128, 160, 192, 240, 256, 320, 384, 40, 56):
+        cells = np.array([remap(c, G) for c in range(G * G)])
+        assert np.array_equal(np.sort(cells), np.arange(G * G)), G
+        if G % 32 == 0:
+            cols = 32
+            for w0 in (0, 64 * 3, G * G - 64):
+                blk = cells[w0:w0 + 64]
+                r, c = blk // G, blk % G
+                assert r.max() - r.min() == 64 // cols - 1 and c.max() - c.min() == cols - 1 and len(set(blk.tolist())) == 64, (G, w0)
+        else:
+            assert np.array_equal(cells, np.arange(G * G))
