@@ -28,6 +28,7 @@ _SIGNATURES = {
     "gfn_refiner_input_fwd_dt": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_vp],
     "gfn_refiner_input_plan_fwd_dt": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_float, c_int, c_int, c_vp, c_i64, c_vp],
     "gfn_corr_softargmax_fwd_dt": [c_vp, c_vp, c_int, c_vp] + [c_int] * 7 + [c_vp],
+    "gfn_corr_softargmax_fwd_ws": [c_vp, c_vp, c_int, c_vp] + [c_int] * 7 + [c_vp, c_i64, c_vp],
     "gfn_grid_sample_fwd": [c_vp, c_vp, c_vp, c_i64] + [c_int] * 6 + [c_vp],
     "gfn_interp_bilinear_fwd": [c_vp, c_vp] + [c_int] * 5 + [c_vp],
     "gfn_interp_bilinear_pair_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
@@ -59,6 +60,7 @@ _SIGNATURES = {
 # entry points that return a size instead of a status
 _SIZE_FUNCS = {
     "gfn_local_corr_scratch_bytes": [c_int, c_int],
+    "gfn_corr_softargmax_ws_bytes": [c_int] * 4,
     "gfn_local_corr_plans": [c_int] * 6,
     "gfn_kde_scratch_floats": [c_int, c_int, c_int, c_int],
     "gfn_kde_sorted_scratch_floats": [c_int, c_int, c_int],

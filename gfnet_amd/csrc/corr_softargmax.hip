@@ -19,6 +19,19 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef GFN_CORR_BF16X3
+#define GFN_CORR_BF16X3 1   // 0: the row-tile path stays on the exact-fp32 matrix core instruction at every channel count
+#endif
+
+// x = h + m + l exactly (three round-to-nearest bf16 pieces of 8 significant bits each cover the 24 of an fp32 value)
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
 
 // KS = k-steps of 2 channels held in registers (compile-time so that the operand array stays in
 // VGPRs: a runtime-indexed register array would go to scratch).
@@ -26,7 +39,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int KS, bool WRITE_VOL, bool WRITE_FLOW, typename FT>
 __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restrict__ f0, const FT *__restrict__ f1,
                                                               float *__restrict__ vol, float *__restrict__ flow, int B,
-                                                              int Bh, int C, int H0, int W0, int H1, int W1, float sqrt_c) {
+                                                              int Bh, int C, int H0, int W0, int H1, int W1, float sqrt_c,
+                                                              const bf16x8 *__restrict__ aimg) {
     const int N0 = H0 * W0, N1 = H1 * W1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int itiles = (N0 + 31) >> 5;
@@ -100,6 +114,120 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
             m = mn;
         };
         const int ntiles = H1 * parts;
+        if constexpr (KS == 32 && GFN_CORR_BF16X3 != 0) {
+            // Round 6, 64-channel maps (GFNet's stride-16 features): the products on the bf16 matrix core instruction with both operands
+            // split three ways (x = h + m + l, exact).  Six of the nine piece products are kept -- h.h, h.m, m.h, m.m, h.l, l.h; the dropped
+            // m.l, l.m, l.l are <= 2^-23 of |a||b|, the size of an fp32 product's own rounding -- in 24 v_mfma_f32_32x32x16_bf16 per tile
+            // (768 matrix cycles) instead of 32 v_mfma_f32_32x32x2_f32 (2 048), and unlike the fp32 instruction they leave the vector ALUs
+            // to the softmax and to the next tile's splitting.  Same accumulator layout, same softmax.  Lane l supplies row / column
+            // l & 31 and channels 16 c + 8 (l >> 5) + e, e = 0..7, of chunk c: plain coalesced NCHW loads as before.
+            bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * c4 + 8 * h + e;
+                    const float v = c < C ? (float)f0b[(size_t)min(c, C - 1) * N0 + ic] : 0.f;
+                    __bf16 ph, pm, pl;
+                    split3(v, ph, pm, pl);
+                    bh[c4][e] = ph; bm[c4][e] = pm; bl[c4][e] = pl;
+                }
+            auto load_raw = [&](float (&a)[32], int t) {
+                const int y = parts == 1 ? t : t >> 1, pp = parts == 1 ? 0 : t & 1;
+                const int jl = y * W1 + min(32 * pp + col, W1 - 1);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[8 * c4 + e] = (float)f1b[(size_t)min(16 * c4 + 8 * h + e, C - 1) * N1 + jl];  // channels >= C meet zeros in b*
+            };
+            if (aimg) {  // (kernel argument: uniform)
+                // the B-positions' operand comes pre-split from the workspace (split_rows_kernel below): every one of the 32 waves that
+                // walk a direction's tiles used to split the same values again -- ~300 of a tile's ~420 vector instructions, on one
+                // wave per SIMD.  Twelve 16-byte loads per tile and lane instead of 32 4-byte ones, nothing but the softmax on the VALU.
+                const bf16x8 *img = aimg + (size_t)b * ntiles * 12 * 64 + lane;
+                bf16x8 a_cur[12], a_nxt[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a_cur[k] = img[k * 64];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) asm volatile("" : "+v"(a_cur[k]));
+                for (int t = 0; t < ntiles; ++t) {
+                    if (t + 1 < ntiles) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) a_nxt[k] = img[((size_t)(t + 1) * 12 + k) * 64];
+                    }
+                    f32x16 accs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc = accs;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[4 + c4], bm[c4], accs, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bm[c4], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bl[c4], accs, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[4 + c4], bh[c4], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[8 + c4], bh[c4], accs, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bh[c4], acc, 0, 0, 0);
+                    }
+                    acc += accs;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) a_cur[k] = a_nxt[k];
+                    if (parts == 1 || !(t & 1)) {
+                        softmax_tile(acc, gxA, parts == 1 ? t : t >> 1);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = ((maskB >> r) & 1u) ? acc[r] : -INFINITY;
+                        softmax_tile(acc, gxB, t >> 1);
+                    }
+                }
+            } else {
+            float r_cur[32], r_nxt[32];
+            load_raw(r_cur, 0);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(r_cur[k]));   // land the first tile before the loop (see below)
+            for (int t = 0; t < ntiles; ++t) {
+                if (t + 1 < ntiles) load_raw(r_nxt, t + 1);
+                bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        __bf16 ph, pm, pl;
+                        split3(r_cur[8 * c4 + e], ph, pm, pl);
+                        ah[c4][e] = ph; am[c4][e] = pm; al[c4][e] = pl;
+                    }
+                // two chains: the small classes and the large ones, smallest terms first inside each; summed at the end
+                f32x16 accs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc = accs;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[c4], bm[c4], accs, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c4], bm[c4], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c4], bl[c4], accs, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[c4], bh[c4], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c4], bh[c4], accs, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c4], bh[c4], acc, 0, 0, 0);
+                }
+                acc += accs;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) r_cur[k] = r_nxt[k];
+                if (parts == 1 || !(t & 1)) {
+                    softmax_tile(acc, gxA, parts == 1 ? t : t >> 1);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = ((maskB >> r) & 1u) ? acc[r] : -INFINITY;
+                    softmax_tile(acc, gxB, t >> 1);
+                }
+            }
+            }
+        } else {
         float a_cur[KS], a_nxt[KS];
         load_row_tile(a_cur, 0);
         // land the first tile before the loop: otherwise the wait-count pass assumes 64 loads in flight at the loop head and
@@ -126,6 +254,7 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
                 for (int r = 0; r < 16; ++r) acc[r] = ((maskB >> r) & 1u) ? acc[r] : -INFINITY;
                 softmax_tile(acc, gxB, t >> 1);
             }
+        }
         }
         m = m / sqrt_c;  // the running maximum was kept in unscaled units
         const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
@@ -212,6 +341,47 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
     }
 }
 
+// Workspace of the split-bf16 row-tile path: the B-positions' operand of every direction, split once.  Image of direction b, row tile t
+// (32 positions of one grid row, as corr_softargmax_kernel walks them), piece p (h, m, l), 16-channel chunk c4: 64 lanes x 16 bytes, lane
+// (h = lane >> 5, col = lane & 31) holding channels 16 c4 + 8 h + e, e = 0..7, of position y W1 + min(32 part + col, W1 - 1).
+template <typename FT>
+__global__ __launch_bounds__(256) void split_rows_kernel(const FT *__restrict__ f0, const FT *__restrict__ f1, bf16x8 *__restrict__ img, int B,
+                                                         int Bh, int C, int H1, int W1) {
+    const int parts = W1 > 32 ? 2 : 1, ntiles = H1 * parts, N1 = H1 * W1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // (b, t, c4, lane)
+    if (idx >= (long)B * ntiles * 4 * 64) return;
+    const int lane = (int)(idx & 63), c4 = (int)((idx >> 6) & 3);
+    const long bt = idx >> 8;
+    const int t = (int)(bt % ntiles), b = (int)(bt / ntiles);
+    const int col = lane & 31, h = lane >> 5;
+    const FT *f1b = b < Bh ? f1 + (size_t)b * C * N1 : f0 + (size_t)(b - Bh) * C * N1;  // (symmetric: equal map sizes, checked by the caller)
+    const int y = parts == 1 ? t : t >> 1, pp = parts == 1 ? 0 : t & 1;
+    const int jl = y * W1 + min(32 * pp + col, W1 - 1);
+    bf16x8 ph, pm, pl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 16 * c4 + 8 * h + e;
+        const float v = c < C ? (float)f1b[(size_t)c * N1 + jl] : 0.f;
+        __bf16 a, m_, l_;
+        split3(v, a, m_, l_);
+        ph[e] = a; pm[e] = m_; pl[e] = l_;
+    }
+    bf16x8 *dst = img + ((size_t)b * ntiles + t) * 12 * 64 + lane;
+    dst[(0 + c4) * 64] = ph;
+    dst[(4 + c4) * 64] = pm;
+    dst[(8 + c4) * 64] = pl;
+}
+
+// bytes of workspace the split-bf16 path wants for this shape (0: the shape does not take it)
+int64_t split_ws_bytes(int B, int C, int H1, int W1) {
+#ifndef GFN_CORR_PRESPLIT
+#define GFN_CORR_PRESPLIT 1   // 0: A/B builds in which every wave splits the operand itself
+#endif
+    if (GFN_CORR_BF16X3 == 0 || GFN_CORR_PRESPLIT == 0 || C <= 32 || C > 64 || W1 < 32 || W1 > 64) return 0;
+    const int64_t ntiles = (int64_t)H1 * (W1 > 32 ? 2 : 1);
+    return (int64_t)B * ntiles * 12 * 64 * 16;
+}
+
 // pos_embed on an explicit volume (model/network.py:430-440): one thread per (b, i), coalesced
 // over i, online softmax over j.  Only used when a caller hands in a volume of its own.
 __global__ __launch_bounds__(256) void pos_embed_kernel(const float *__restrict__ vol, float *__restrict__ flow, int B,
@@ -254,18 +424,29 @@ int check_args(const void *f0, const void *f1, int B, int C, int H0, int W0, int
 
 template <bool WV, bool WF, typename FT>
 int launch_corr(const FT *f0, const FT *f1, float *vol, float *flow, int B, int Bh, int C, int H0, int W0, int H1,
-                int W1, hipStream_t stream) {
+                int W1, hipStream_t stream, void *ws = nullptr, int64_t ws_bytes = 0) {
     const int waves = B * ((H0 * W0 + 31) / 32);
     const dim3 grid((waves + 3) / 4), block(256);
     const float sc = (float)sqrt((double)C);
+    const bf16x8 *aimg = nullptr;
+    if (WF && !WV) {
+        const int64_t need = split_ws_bytes(B, C, H1, W1);
+        if (need > 0 && ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0) {   // without a workspace the kernel splits the operand itself
+            const long items = (long)B * H1 * (W1 > 32 ? 2 : 1) * 4 * 64;
+            hipLaunchKernelGGL((split_rows_kernel<FT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, f0, f1,
+                               static_cast<bf16x8 *>(ws), B, Bh, C, H1, W1);
+            if (int e = gfn::check_launch("split_rows_kernel")) return e;
+            aimg = static_cast<const bf16x8 *>(ws);
+        }
+    }
     if (C <= 16)
-        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<8, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
     else if (C <= 32)
-        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<16, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
     else if (C <= 64)
-        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<32, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
     else
-        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc);
+        hipLaunchKernelGGL((corr_softargmax_kernel<64, WV, WF, FT>), grid, block, 0, stream, f0, f1, vol, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
     return gfn::check_launch("corr_softargmax_kernel");
 }
 
@@ -293,6 +474,24 @@ GFN_EXPORT int gfn_corr_softargmax_fwd_dt(const void *f0, const void *f1, int dt
     if (B == 0) return GFN_OK;
     return launch_corr<false, true>(static_cast<const _Float16 *>(f0), static_cast<const _Float16 *>(f1), nullptr, flow, B, symmetric ? B / 2 : B, C,
                                     H0, W0, H1, W1, (hipStream_t)stream);
+}
+
+GFN_EXPORT int64_t gfn_corr_softargmax_ws_bytes(int B, int C, int H1, int W1) { return split_ws_bytes(B, C, H1, W1); }
+
+GFN_EXPORT int gfn_corr_softargmax_fwd_ws(const void *f0, const void *f1, int dtype, float *flow, int B, int C, int H0, int W0, int H1,
+                                          int W1, int symmetric, void *ws, int64_t ws_bytes, gfn_stream_t stream) {
+    if (dtype != GFN_F32 && dtype != GFN_F16) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: feature dtype must be GFN_F32 or GFN_F16");
+    if (int e = check_args(f0, f1, B, C, H0, W0, H1, W1)) return e;
+    if (!flow) return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: null flow");
+    if (symmetric && ((B & 1) || H0 != H1 || W0 != W1))
+        return gfn::fail(GFN_ERR_INVALID_ARG, "corr_softargmax: symmetric needs an even batch and equal map sizes");
+    if (B == 0) return GFN_OK;
+    const int Bh = symmetric ? B / 2 : B;
+    if (dtype == GFN_F16)
+        return launch_corr<false, true>(static_cast<const _Float16 *>(f0), static_cast<const _Float16 *>(f1), nullptr, flow, B, Bh, C, H0, W0, H1, W1,
+                                        (hipStream_t)stream, ws, ws_bytes);
+    return launch_corr<false, true>(static_cast<const float *>(f0), static_cast<const float *>(f1), nullptr, flow, B, Bh, C, H0, W0, H1, W1,
+                                    (hipStream_t)stream, ws, ws_bytes);
 }
 
 GFN_EXPORT int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C,

@@ -61,8 +61,12 @@ def corr_softargmax(feat0, feat1, symmetric=False):
         raise ValueError("feat0/feat1 batch or channel mismatch")
     nb = 2 * B if symmetric else B
     flow = torch.empty((nb, 2, H0, W0), device=dev, dtype=torch.float32)
-    check(_L().gfn_corr_softargmax_fwd_dt(ptr(f0), ptr(f1), dt0, ptr(flow), nb, C, H0, W0, H1, W1, 1 if symmetric else 0,
-                                          stream_ptr(dev)), "gfn_corr_softargmax_fwd")
+    # workspace of the split-bf16 path (64-channel maps): the caller owns every buffer (include/gfnet_hip.h); a fresh tensor per call
+    # (the caching allocator hands the same block back; not the per-stream scratch, whose header the local correlation keeps zeroed)
+    nws = int(_L().gfn_corr_softargmax_ws_bytes(nb, C, H1, W1))
+    ws = torch.empty(nws, device=dev, dtype=torch.uint8) if nws > 0 else None
+    check(_L().gfn_corr_softargmax_fwd_ws(ptr(f0), ptr(f1), dt0, ptr(flow), nb, C, H0, W0, H1, W1, 1 if symmetric else 0,
+                                          ptr(ws), nws, stream_ptr(dev)), "gfn_corr_softargmax_fwd")
     return flow
 
 

@@ -131,6 +131,16 @@ int gfn_corr_softargmax_fwd(const float *f0, const float *f1, float *flow, int B
 /* The same with the feature maps stored as dtype = GFN_F32 or GFN_F16 (widened on load; products and sums fp32). */
 int gfn_corr_softargmax_fwd_dt(const void *f0, const void *f1, int dtype, float *flow, int B, int C, int H0, int W0, int H1, int W1,
                                int symmetric, gfn_stream_t stream);
+/* The same with a caller-owned workspace (round 6).  On 33..64-channel maps whose rows are 32..64 positions wide (GFNet's stride-16
+ * features, model/network.py:251-252) the products run on the bf16 matrix core instruction with both operands split three ways
+ * (x = h + m + l exactly; six of the nine piece products kept, the dropped ones <= 2^-23 of |a||b|: measured closer to a float64
+ * evaluation than the fp32 fma chains of the calls above); with ws_bytes >= gfn_corr_softargmax_ws_bytes(B, C, H1, W1) the
+ * B-positions' operand is split ONCE into ws (16-byte aligned device memory, contents undefined afterwards) instead of by every
+ * wave that walks it.  ws == NULL or too small: same results, slower.  gfn_corr_softargmax_ws_bytes returns 0 for shapes that
+ * take no workspace. */
+int64_t gfn_corr_softargmax_ws_bytes(int B, int C, int H1, int W1);
+int gfn_corr_softargmax_fwd_ws(const void *f0, const void *f1, int dtype, float *flow, int B, int C, int H0, int W0, int H1, int W1,
+                               int symmetric, void *ws, int64_t ws_bytes, gfn_stream_t stream);
 int gfn_corr_volume_fwd(const float *f0, const float *f1, float *vol, float *flow_or_null, int B, int C, int H0, int W0,
                         int H1, int W1, gfn_stream_t stream);
 int gfn_pos_embed_fwd(const float *vol, float *flow, int B, int H0, int W0, int H1, int W1, gfn_stream_t stream);

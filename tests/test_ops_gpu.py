@@ -57,6 +57,48 @@ def test_corr_softargmax_vs_oracle(C, H0, H1, B):
     assert_close(host(ops.corr_softargmax(dev(f0), dev(f1))), oracle.corr_softargmax(f0, f1), TOL, "flow")
 
 
+@pytest.mark.parametrize("C,H,W,B,sym,half", [(64, 32, 32, 4, True, False), (64, 48, 48, 2, True, False), (64, 33, 40, 2, False, False),
+                                              (48, 32, 32, 2, True, False), (64, 32, 32, 2, True, True), (64, 64, 64, 1, False, False)])
+def test_corr_softargmax_split_bf16_with_and_without_workspace(C, H, W, B, sym, half):
+    """Round 6: on 33..64-channel maps with 32..64-position rows the products run on the bf16 matrix core instruction with both operands
+    split three ways; gfn_corr_softargmax_fwd_ws splits the B-positions' operand once into a caller-owned workspace.  Through the C ABI:
+    with a workspace == without one (the same pieces, the same MFMA order: bit for bit), both within the flow tolerance of the oracle
+    (measured ~1e-7: closer to float64 than the fp32 chains), symmetric batches against the two one-way calls, fp16 maps against their
+    widened copy, a too-small / misaligned / absent workspace is simply not used, and the size query is 0 for shapes that take none."""
+    from gfnet_amd import _lib, ops
+
+    L = _lib.lib()
+    f0 = 2 * synth.lattice_normalish((B, C, H, W), 171)
+    f1 = 2 * synth.lattice_normalish((B, C, H, W), 172)
+    a, b = dev(f0), dev(f1)
+    if half:
+        a, b = a.half(), b.half()
+    nb = 2 * B if sym else B
+    need = int(L.gfn_corr_softargmax_ws_bytes(nb, C, H, W))
+    assert need == nb * H * (2 if W > 32 else 1) * 12 * 64 * 16
+    assert int(L.gfn_corr_softargmax_ws_bytes(nb, 16, H, W)) == 0 and int(L.gfn_corr_softargmax_ws_bytes(nb, C, 16, 16)) == 0
+
+    def run(ws, nbytes):
+        flow = torch.empty((nb, 2, H, W), device="cuda")
+        _lib.check(L.gfn_corr_softargmax_fwd_ws(_lib.ptr(a), _lib.ptr(b), _lib.GFN_F16 if half else _lib.GFN_F32, _lib.ptr(flow), nb, C, H, W, H, W,
+                                                1 if sym else 0, _lib.ptr(ws), nbytes, _lib.stream_ptr(a.device)), "gfn_corr_softargmax_fwd_ws")
+        return host(flow)
+
+    ws = torch.empty(need + 16, device="cuda", dtype=torch.uint8)
+    with_ws = run(ws, need)
+    assert np.array_equal(with_ws, run(None, 0))
+    assert np.array_equal(with_ws, run(ws, need - 1))                 # too small: not used
+    assert np.array_equal(with_ws, run(ws[8:], need))                 # misaligned: not used
+    assert np.array_equal(with_ws, host(ops.corr_softargmax(a, b, symmetric=sym)))
+    af, bf = host(a.float()), host(b.float())
+    ref = oracle.corr_softargmax(af, bf)
+    if sym:
+        ref = np.concatenate((ref, oracle.corr_softargmax(bf, af)))
+    assert_close(with_ws, ref, TOL, "flow")
+    if half:
+        assert np.array_equal(with_ws, host(ops.corr_softargmax(a.float(), b.float(), symmetric=sym)))
+
+
 # ---- A8 kde -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", [512, 4096])
 def test_g3_golden_kde(N):
