@@ -341,6 +341,122 @@ __global__ __launch_bounds__(256) void corr_softargmax_kernel(const FT *__restri
     }
 }
 
+// The row-tile path on pre-split operand images as a kernel of its own (round 6): nothing of the general kernel's other paths lives in
+// its register allocation, so two waves fit a SIMD (<= 256 registers; the general kernel sits at 292 = one wave) and the image loads of
+// one wave hide behind the other's matrix work.  PARTS = row tiles per grid row (1: W1 == 32, 2: 33..64).
+template <int PARTS, typename FT>
+__global__ __launch_bounds__(256, 2) void corr_softargmax_img_kernel(const FT *__restrict__ f0, const FT *__restrict__ f1, float *__restrict__ flow,
+                                                                     int B, int Bh, int C, int H0, int W0, int H1, int W1, float sqrt_c,
+                                                                     const bf16x8 *__restrict__ aimg) {
+    const int N0 = H0 * W0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int itiles = (N0 + 31) >> 5;
+    const int wid = blockIdx.x * 4 + wave;
+    if (wid >= B * itiles) return;
+    const int b = wid / itiles, i0 = (wid - b * itiles) << 5;
+    const int col = lane & 31, h = lane >> 5;
+    const int i = i0 + col;
+    const int ic = min(i, N0 - 1);
+    const FT *f0b = b < Bh ? f0 + (size_t)b * C * N0 : f1 + (size_t)(b - Bh) * C * N0;
+    bf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * c4 + 8 * h + e;
+            const float v = c < C ? (float)f0b[(size_t)min(c, C - 1) * N0 + ic] : 0.f;
+            __bf16 ph, pm, pl;
+            split3(v, ph, pm, pl);
+            bh[c4][e] = ph; bm[c4][e] = pm; bl[c4][e] = pl;
+        }
+    const float x_lo = (float)(-1 + 1.0 / W1), x_hi = (float)(1 - 1.0 / W1);
+    const float y_lo = (float)(-1 + 1.0 / H1), y_hi = (float)(1 - 1.0 / H1);
+    float m = -INFINITY, l = 0.f, ax = 0.f, ay = 0.f;
+    const float e_scale = 1.4426950408889634f / sqrt_c;
+    float gxA[16], gxB[PARTS == 2 ? 16 : 1];
+    unsigned maskB = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+        gxA[r] = gfn::linspace_at(x_lo, x_hi, W1, min(o, W1 - 1));
+        if (PARTS == 2) {
+            gxB[r] = gfn::linspace_at(x_lo, x_hi, W1, min(32 + o, W1 - 1));
+            maskB |= (32 + o < W1 ? 1u : 0u) << r;
+        }
+    }
+    auto softmax_tile = [&](f32x16 acc, const float *gx, int y) {   // as in corr_softargmax_kernel
+        float mt = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
+        const float mn = fmaxf(m, mt);
+        const float sc = __builtin_amdgcn_exp2f((m - mn) * e_scale);
+        float lt = 0.f, axt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f((acc[r] - mn) * e_scale);
+            lt += e;
+            axt = fmaf(e, gx[r], axt);
+        }
+        const float gy = gfn::linspace_at(y_lo, y_hi, H1, y);
+        l = fmaf(l, sc, lt);
+        ax = fmaf(ax, sc, axt);
+        ay = fmaf(ay, sc, lt * gy);
+        m = mn;
+    };
+    const int ntiles = H1 * PARTS;
+    const bf16x8 *img = aimg + (size_t)b * ntiles * 12 * 64 + lane;
+    // (issuing the products of tile t + 1 in front of the softmax of tile t -- a software pipeline over the tiles, 238 registers -- measured
+    // SLOWER: 72 against 64 us; the second wave of the SIMD already fills the matrix pipe under this wave's exponentials)
+    bf16x8 a_cur[12], a_nxt[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a_cur[k] = img[k * 64];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) asm volatile("" : "+v"(a_cur[k]));   // land the first tile before the loop (see corr_softargmax_kernel)
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a_nxt[k] = img[((size_t)(t + 1) * 12 + k) * 64];
+        }
+        // two chains: the small classes and the large ones, smallest terms first inside each; summed at the end
+        f32x16 accs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc = accs;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[4 + c4], bm[c4], accs, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bm[c4], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bl[c4], accs, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[4 + c4], bh[c4], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[8 + c4], bh[c4], accs, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[c4], bh[c4], acc, 0, 0, 0);
+        }
+        acc += accs;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a_cur[k] = a_nxt[k];
+        if (PARTS == 1 || !(t & 1)) {
+            softmax_tile(acc, gxA, PARTS == 1 ? t : t >> 1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = ((maskB >> r) & 1u) ? acc[r] : -INFINITY;
+            softmax_tile(acc, gxB, t >> 1);
+        }
+    }
+    m = m / sqrt_c;  // the running maximum was kept in unscaled units
+    const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), ax2 = __shfl_xor(ax, 32), ay2 = __shfl_xor(ay, 32);
+    const float mn = fmaxf(m, m2);
+    const float s1 = __expf(m - mn), s2 = __expf(m2 - mn);
+    const float lt = l * s1 + l2 * s2;
+    const float fx = (ax * s1 + ax2 * s2) / lt, fy = (ay * s1 + ay2 * s2) / lt;
+    if (h == 0 && i < N0) {
+        flow[((size_t)b * 2 + 0) * N0 + i] = fx;
+        flow[((size_t)b * 2 + 1) * N0 + i] = fy;
+    }
+}
+
 // Workspace of the split-bf16 row-tile path: the B-positions' operand of every direction, split once.  Image of direction b, row tile t
 // (32 positions of one grid row, as corr_softargmax_kernel walks them), piece p (h, m, l), 16-channel chunk c4: 64 lanes x 16 bytes, lane
 // (h = lane >> 5, col = lane & 31) holding channels 16 c4 + 8 h + e, e = 0..7, of position y W1 + min(32 part + col, W1 - 1).
@@ -437,6 +553,15 @@ int launch_corr(const FT *f0, const FT *f1, float *vol, float *flow, int B, int 
                                static_cast<bf16x8 *>(ws), B, Bh, C, H1, W1);
             if (int e = gfn::check_launch("split_rows_kernel")) return e;
             aimg = static_cast<const bf16x8 *>(ws);
+        }
+    }
+    if constexpr (WF && !WV) {
+        if (aimg) {
+            if (W1 > 32)
+                hipLaunchKernelGGL((corr_softargmax_img_kernel<2, FT>), grid, block, 0, stream, f0, f1, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
+            else
+                hipLaunchKernelGGL((corr_softargmax_img_kernel<1, FT>), grid, block, 0, stream, f0, f1, flow, B, Bh, C, H0, W0, H1, W1, sc, aimg);
+            return gfn::check_launch("corr_softargmax_img_kernel");
         }
     }
     if (C <= 16)
