@@ -115,8 +115,20 @@ def ptr(t):
     return c_vp(t.data_ptr()) if t is not None else c_vp(0)
 
 
+# the current stream's raw handle: torch.cuda.current_stream() builds a Stream object per call (~4.5 us; a step makes ~150 calls and the
+# three-scene workload is bound by the host's launch rate), the C hook returns the handle itself
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def current_stream_handle(device):
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream_ptr(device):
-    return c_vp(torch.cuda.current_stream(device).cuda_stream)
+    return c_vp(current_stream_handle(device))
 
 
 def require_gpu(*tensors):
@@ -155,7 +167,7 @@ def scratch(device, nbytes):
     """A per-(device, stream), grow-only int32 scratch buffer.  Reuse is stream-ordered: any number of models may share it on
     one stream (their launches cannot overlap), work on different streams gets different buffers; one host thread per
     stream.  Dropped as a whole after any failed call (check())."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.type, device.index, current_stream_handle(device) if device.type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         # a buffer that is outgrown is RETIRED, not freed: a hipGraph captured on this stream keeps launching kernels with its

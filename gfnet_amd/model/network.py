@@ -410,7 +410,8 @@ class GFNet(nn.Module):
     @torch.inference_mode()
     def match_first_pass(self, pyr0, pyr1):
         """The first (initial-resolution) coarse-to-fine pass: network.py:285-331.  Returns its corresps."""
-        self.train(False)
+        if self.training:  # (train() walks every submodule: 50 attribute writes per call on a host-bound path)
+            self.train(False)
         return self.forward_pyramids(pyr0, pyr1, (self.h_resized, self.w_resized), symmetric=self.symmetric)
 
     @torch.inference_mode()
@@ -420,7 +421,10 @@ class GFNet(nn.Module):
         corresps_up = None
         if self.upsample_preds:
             hs, ws = self.upsample_res
-            self.num_grid_up, self.radius_up, self.num_itr_up = self.upsample_grids(hs)
+            up = self.upsample_grids(hs)
+            if getattr(self, "_up_key", None) != (hs, tuple(self.radius), tuple(self.num_itr)):  # nn.Module.__setattr__ is not free: set once
+                self.num_grid_up, self.radius_up, self.num_itr_up = up
+                self._up_key = (hs, tuple(self.radius), tuple(self.num_itr))
             if pyr0_up is None:
                 raise ValueError("upsample_preds=True needs the feature pyramids of the upsample resolution")
             sf = math.sqrt(hs * ws / (self.w_resized * self.h_resized))
